@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz FROM THE REFERENCE ITSELF (authoring container only).
+
+What runs here is the reference, not this repository's code:
+
+* the reference's compiled arithmetic core (oracle/_ref/libxgpr_ref.so, built
+  by oracle/Makefile from the two nanobind-free files of
+  /root/reference/src/xGPR/random_feature_generation/cpu_rf_gen/shared_fht_functions/),
+* the reference's Python package, imported from /root/reference/src with that
+  compiled core registered as the stand-in for its own (offline-unbuildable,
+  nanobind-based) extension module ``xGPR.xgpr_cpu_rfgen_cpp_ext``.
+
+The outputs are data only (inputs + expected outputs); the settings are the
+ones the reference's tests use (file:line cited next to each block), trimmed
+in row count so the fixtures stay small.  /root/reference does not travel to
+the GPU box: tests read only the .npz files written here.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+from math import ceil
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+REF_SRC = "/root/reference/src"
+REF_TESTDATA = "/root/reference/tests/test_data"
+
+from oracle import oracle as orc  # noqa: E402
+
+orc.build(ref=True)
+REF = orc.RefCore()
+
+
+def _standin_module():
+    """The reference's extension-module surface (cpu_rf_gen/xgpr_cpu_rfgen_cpp_ext.cpp:24-146)
+    served by the reference's own compiled core."""
+    m = types.ModuleType("xGPR.xgpr_cpu_rfgen_cpp_ext")
+    for name in ["cpuFastHadamardTransform", "cpuFastHadamardTransform2D", "cpuSRHT",
+                 "cpuRBFFeatureGen", "cpuRBFGrad", "cpuConv1dMaxpool", "cpuConv1dFGen",
+                 "cpuConvGrad"]:
+        setattr(m, name, getattr(REF, name))
+
+    def cpuMiniARDGrad(*a, **k):
+        raise NotImplementedError("MiniARD is out of scope")
+    m.cpuMiniARDGrad = cpuMiniARDGrad
+    return m
+
+
+def import_reference():
+    sys.modules["xGPR.xgpr_cpu_rfgen_cpp_ext"] = _standin_module()
+    sys.path.insert(0, REF_SRC)
+    import xGPR  # noqa: F401
+    return xGPR
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+# ---------------------------------------------------------------- G1: bare FHT
+def g1_fht():
+    """tests/fht_operations_tests/test_basic_rfgen.py:26-47, :98-138 (shapes there go up to
+    (250,1,4096)); here 8 rows x P in {2,4,32,1024,4096} + one 3-D case."""
+    rng = np.random.default_rng(123)
+    out = {}
+    for P in [2, 4, 32, 1024, 4096]:
+        x = rng.uniform(-10, 10, size=(8, P))
+        x32 = x.astype(np.float32)
+        x64 = x32.astype(np.float64)   # one stored input serves both precisions
+        y32, y64 = x32.copy(), x64.copy()
+        REF.cpuFastHadamardTransform2D(y32)
+        REF.cpuFastHadamardTransform2D(y64)
+        out[f"x_{P}"] = x32
+        out[f"y32_{P}"] = y32
+        out[f"y64_{P}"] = y64
+    x = rng.uniform(-10, 10, size=(5, 3, 64)).astype(np.float32)
+    y32, y64 = x.copy(), x.astype(np.float64)
+    REF.cpuFastHadamardTransform(y32)
+    REF.cpuFastHadamardTransform(y64)
+    out.update(x3d=x, y3d32=y32, y3d64=y64)
+    save("g1_fht.npz", **out)
+
+
+# ---------------------------------------------------------------- G2: SORF-RBF
+def g2_rbf():
+    """tests/fht_operations_tests/test_rbf_rfgen.py:26-68 (xdim/num_freqs list) with the
+    set-up of :192-211 (seed 123, radem -> chi -> uniform[-10,10] inputs)."""
+    from scipy.stats import chi
+    settings = [((10, 50), 64, False, 6), ((10, 3), 64, False, 6), ((3, 2003), 2000, False, 3),
+                ((11, 1076), 8192, False, 2), ((231, 856), 2000, True, 4),
+                ((16, 32), 256, True, 8), ((16, 256), 2048, True, 4), ((8, 1024), 4096, True, 4),
+                ((8, 512), 1000, False, 4)]
+    out = {"n_settings": np.int64(len(settings))}
+    for si, (xdim, num_freqs, intercept, rows) in enumerate(settings):
+        pd = 2 ** ceil(np.log2(max(xdim[-1], 2)))
+        nblocks = ceil(num_freqs / pd) if pd < num_freqs else 1
+        rng = np.random.default_rng(123)
+        radem = rng.choice(np.asarray([-1, 1], dtype=np.int8), size=(3, 1, nblocks * pd),
+                           replace=True)
+        chi_arr = chi.rvs(df=pd, size=num_freqs, random_state=123)
+        x = rng.uniform(low=-10.0, high=10.0, size=(xdim[0], xdim[1]))[:rows]
+        x32 = np.ascontiguousarray(x.astype(np.float32))
+        x64 = x32.astype(np.float64)
+        chi32 = chi_arr.astype(np.float32)
+        chi64 = chi32.astype(np.float64)
+        o32 = np.zeros((rows, 2 * num_freqs))
+        o64 = np.zeros((rows, 2 * num_freqs))
+        REF.cpuRBFFeatureGen(x32, o32, radem, chi32, intercept)
+        REF.cpuRBFFeatureGen(x64, o64, radem, chi64, intercept)
+        out[f"x_{si}"] = x32
+        out[f"radem_{si}"] = radem
+        out[f"chi_{si}"] = chi32
+        out[f"intercept_{si}"] = np.bool_(intercept)
+        out[f"out32_{si}"] = o32
+        out[f"out64_{si}"] = o64
+        if si in (0, 4):   # gradient (test_rbf_rfgen.py:51-68): sigma 0.7, unscaled input
+            sigma = 0.7
+            g32 = np.zeros((rows, 2 * num_freqs, 1))
+            g64 = np.zeros((rows, 2 * num_freqs, 1))
+            go32 = np.zeros((rows, 2 * num_freqs))
+            go64 = np.zeros((rows, 2 * num_freqs))
+            REF.cpuRBFGrad(x32, go32, g32, radem, chi32, sigma, intercept)
+            REF.cpuRBFGrad(x64, go64, g64, radem, chi64, sigma, intercept)
+            out[f"sigma_{si}"] = np.float64(sigma)
+            out[f"gout32_{si}"] = go32
+            out[f"grad32_{si}"] = g32
+            out[f"gout64_{si}"] = go64
+            out[f"grad64_{si}"] = g64
+    save("g2_rbf.npz", **out)
+
+
+def _conv_setup(ndatapoints, kernel_width, aa_dim, num_aas, num_freqs, maxpool):
+    """tests/fht_operations_tests/conv_testing_functions.py:12-41."""
+    dim2 = 2 ** ceil(np.log2(kernel_width * aa_dim))
+    radem_size = ceil(num_freqs / dim2) * dim2
+    rng = np.random.default_rng(123)
+    xdata = rng.uniform(low=-10.0, high=10.0, size=(ndatapoints, num_aas, aa_dim))
+    s_mat = rng.uniform(size=num_freqs)
+    radem = rng.choice(np.asarray([-1, 1], dtype=np.int8), size=(3, 1, radem_size), replace=True)
+    seqlen = rng.integers(low=kernel_width + 1, high=num_aas + 1,
+                          size=ndatapoints).astype(np.int32)
+    return xdata, s_mat, radem, seqlen
+
+
+# ---------------------------------------------------------------- G3: conv SORF-RBF
+def g3_conv():
+    """tests/fht_operations_tests/test_conv1d_fht.py:25-33 (seven settings), :93-110
+    (normalisation 1, 2), :49-57 (gradient).  Row counts trimmed; the (10,256,512,333)
+    setting is shortened to 40 positions (still P = 8192 with > 1 k-mer)."""
+    # kernel_width, num_aas, aa_dim, num_freqs, sigma, n, scaling
+    settings = [(9, 23, 21, 1000, 0.5, 4, 0), (5, 56, 2, 62, 0.5, 6, 0), (9, 23, 21, 1000, 1, 4, 0),
+                (7, 202, 105, 784, 1, 2, 0), (9, 10, 2000, 4096, 1, 2, 0),
+                (10, 11, 200, 784, 1, 3, 0), (10, 40, 512, 333, 1, 2, 0),
+                (7, 53, 105, 784, 1, 3, 1), (7, 53, 105, 784, 1, 3, 2),
+                (9, 64, 21, 1024, 1, 4, 1)]
+    out = {"n_settings": np.int64(len(settings))}
+    for si, (kw, num_aas, aa_dim, nf, sigma, n, scaling) in enumerate(settings):
+        xdata, s_mat, radem, seqlen = _conv_setup(n, kw, aa_dim, num_aas, nf, False)
+        x32 = np.ascontiguousarray((xdata * sigma).astype(np.float32))
+        x64 = x32.astype(np.float64)
+        chi32 = s_mat.astype(np.float32)
+        chi64 = chi32.astype(np.float64)
+        o32 = np.zeros((n, 2 * nf))
+        o64 = np.zeros((n, 2 * nf))
+        REF.cpuConv1dFGen(x32, o32, radem, chi32, seqlen, kw, scaling)
+        REF.cpuConv1dFGen(x64, o64, radem, chi64, seqlen, kw, scaling)
+        out[f"x_{si}"] = x32
+        out[f"radem_{si}"] = radem
+        out[f"chi_{si}"] = chi32
+        out[f"seqlen_{si}"] = seqlen
+        out[f"conv_width_{si}"] = np.int64(kw)
+        out[f"scaling_{si}"] = np.int64(scaling)
+        out[f"out32_{si}"] = o32
+        out[f"out64_{si}"] = o64
+    # gradient, test_conv1d_fht.py:49-57: (9, 23, 21, 128), sigma 0.5
+    kw, num_aas, aa_dim, nf, sigma, n = 9, 23, 21, 128, 0.5, 4
+    xdata, s_mat, radem, seqlen = _conv_setup(n, kw, aa_dim, num_aas, nf, False)
+    x32 = np.ascontiguousarray(xdata.astype(np.float32))
+    chi32 = s_mat.astype(np.float32)
+    for tag, x, c in (("32", x32, chi32), ("64", x32.astype(np.float64), chi32.astype(np.float64))):
+        o = np.zeros((n, 2 * nf))
+        g = np.zeros((n, 2 * nf, 1))
+        REF.cpuConvGrad(x, o, radem, c, seqlen, g, sigma, kw, 1)
+        out[f"g_out{tag}"] = o
+        out[f"g_grad{tag}"] = g
+    out.update(g_x=x32, g_radem=radem, g_chi=chi32, g_seqlen=seqlen, g_conv_width=np.int64(kw),
+               g_sigma=np.float64(sigma), g_scaling=np.int64(1))
+    save("g3_conv.npz", **out)
+
+
+# ---------------------------------------------------------------- G4: conv max-pool
+def g4_maxpool():
+    """tests/fht_operations_tests/test_maxpool_rfgen.py:23-55; rows trimmed, the
+    (5,512,1024,1024) setting shortened to 40 positions."""
+    settings = [(9, 23, 21, 130, 4), (15, 23, 1060, 8194, 2), (5, 56, 2, 62, 6),
+                (5, 56, 256, 500, 3), (5, 40, 1024, 1024, 2)]
+    out = {"n_settings": np.int64(len(settings))}
+    for si, (kw, num_aas, aa_dim, nf, n) in enumerate(settings):
+        xdata, s_mat, radem, seqlen = _conv_setup(n, kw, aa_dim, num_aas, nf, True)
+        x32 = np.ascontiguousarray(xdata.astype(np.float32))
+        x64 = x32.astype(np.float64)
+        chi32 = s_mat.astype(np.float32)
+        o32 = np.zeros((n, nf), np.float32)
+        o64 = np.zeros((n, nf), np.float32)
+        REF.cpuConv1dMaxpool(x32, o32, radem, chi32, seqlen, kw)
+        REF.cpuConv1dMaxpool(x64, o64, radem, chi32.astype(np.float64), seqlen, kw)
+        out[f"x_{si}"] = x32
+        out[f"radem_{si}"] = radem
+        out[f"chi_{si}"] = chi32
+        out[f"seqlen_{si}"] = seqlen
+        out[f"conv_width_{si}"] = np.int64(kw)
+        out[f"out32_{si}"] = o32
+        out[f"out64_{si}"] = o64
+    save("g4_maxpool.npz", **out)
+
+
+# ---------------------------------------------------------------- G5: SRHT
+def g5_srht():
+    """tests/fht_operations_tests/test_basic_rfgen.py:49-56, :140-178 (shapes (150,256),
+    (304,512), (5,2048)); rows trimmed to 6, plus the preconditioner widths 8192/32768."""
+    rng = np.random.default_rng(123)
+    out = {}
+    for P, rows in [(256, 6), (512, 6), (2048, 5), (8192, 2), (32768, 2)]:
+        x = rng.uniform(-10, 10, size=(rows, P)).astype(np.float32)
+        radem = rng.choice(np.asarray([-1, 1], dtype=np.int8), size=(P), replace=True)
+        y32, y64 = x.copy(), x.astype(np.float64)
+        REF.cpuSRHT(y32, radem)
+        REF.cpuSRHT(y64, radem)
+        out[f"x_{P}"] = x
+        out[f"radem_{P}"] = radem
+        out[f"y32_{P}"] = y32
+        out[f"y64_{P}"] = y64
+    save("g5_srht.npz", **out)
+
+
+# ---------------------------------------------------------------- G6: parameter draws
+def g6_draws(xgpr):
+    """Kernel parameter draws by the reference's own kernel classes:
+    kernels/basic_kernels/sorf_kernel_baseclass.py:71-84, matern.py:50-54, cauchy.py:39-41,
+    convolution_kernels/conv_kernel_baseclass.py:85-99, kernels/srht_compressor.py:61-65."""
+    from xGPR.kernels import KERNEL_NAME_TO_CLASS
+    from xGPR.kernels.srht_compressor import SRHTCompressor
+    out = {}
+    cases = [("cfg1_RBF", "RBF", (1, 32), 512, {}),
+             ("cfg2_RBF", "RBF", (1, 256), 4096, {}),
+             ("cfg3_Matern", "Matern", (1, 1024), 8192, {"matern_nu": 5 / 2}),
+             ("cfg3_Cauchy", "Cauchy", (1, 1024), 8192, {}),
+             ("cfg5_RBF", "RBF", (1, 512), 32768, {}),
+             ("fix_RBF", "RBF", (1, 84), 4096, {}),
+             ("small_RBF", "RBF", (1, 3), 64, {}),
+             ("cfg4_Conv1dRBF", "Conv1dRBF", (1, 512, 21), 16384, {"conv_width": 9}),
+             ("graph_GraphRBF", "GraphRBF", (1, 30, 12), 1024, {}),
+             ("conv_Conv1dMatern", "Conv1dMatern", (1, 60, 21), 2048,
+              {"conv_width": 5, "matern_nu": 3 / 2})]
+    for tag, kname, xdim, rffs, parms in cases:
+        cls = KERNEL_NAME_TO_CLASS[kname]
+        k = cls(xdim, rffs, random_seed=123, device="cpu", kernel_spec_parms=parms)
+        out[f"{tag}_radem"] = np.asarray(k.radem_diag)
+        out[f"{tag}_chi"] = np.asarray(k.chi_arr)
+    for tag, rank, m in [("srht_256_4096", 256, 4096), ("srht_512_8192", 512, 8192),
+                         ("srht_64_512", 64, 512), ("srht_100_1000", 100, 1000)]:
+        c = SRHTCompressor(rank, m, random_seed=123, device="cpu")
+        out[f"{tag}_radem"] = c.radem
+        out[f"{tag}_col_sampler"] = c.col_sampler
+    save("g6_draws.npz", **out)
+
+
+# ---------------------------------------------------------------- G7: CG iterates
+def g7_cg(xgpr):
+    """BASELINE cfg1-sized synthetic problem (N=2000, d=32, M=512, chunk 500, seed 123,
+    (lambda, sigma) = (0.277, 0.358)) pushed through the reference's own
+    build_regression_dataset, RBF kernel, RandNysPreconditioner and CPU_ConjugateGrad
+    (fitting_toolkit/cg_tools.py:203-302, cg_fitting_toolkit.py:18-70).  Per-iteration
+    iterates come from re-running the (deterministic, x0 = 0) solver with max_iter = j."""
+    import warnings
+    from xGPR.data_handling.dataset_builder import build_regression_dataset
+    from xGPR.kernels import KERNEL_NAME_TO_CLASS
+    from xGPR.preconditioners.rand_nys_preconditioners import RandNysPreconditioner
+    from xGPR.fitting_toolkit.cg_fitting_toolkit import cg_fit_lib_internal
+    from xGPR.scoring_toolkit.exact_nmll_calcs import calc_zty
+
+    rng = np.random.default_rng(123)
+    n, d, m = 2000, 32, 512
+    x = rng.uniform(-1, 1, size=(n, d))
+    a = rng.standard_normal(d)
+    y = np.sin(x @ a) + 0.1 * rng.standard_normal(n)
+    x = x.astype(np.float32).astype(np.float64)
+    hyper = np.array([0.277, 0.358])
+    ds = build_regression_dataset(x, y, chunk_size=500)
+    out = dict(x=x.astype(np.float32), y=y, hyperparams=hyper, chunk_size=np.int64(500),
+               num_rffs=np.int64(m), y_mean=np.float64(ds.get_ymean()),
+               y_std=np.float64(ds.get_ystd()))
+
+    for kname, parms in [("RBF", {}), ("Matern", {"matern_nu": 5 / 2})]:
+        kern = KERNEL_NAME_TO_CLASS[kname]((n, d), m, random_seed=123, device="cpu",
+                                           kernel_spec_parms=parms)
+        kern.set_hyperparams(hyper, logspace=False)
+        z_first = kern.transform_x(x[:8])
+        out[f"{kname}_z_first8"] = z_first
+        zty, yty = calc_zty(ds, kern)
+        out[f"{kname}_zty"] = zty
+        out[f"{kname}_yty"] = np.float64(yty)
+        for ptag, method, rank in [("none", None, 0), ("srht", "srht", 64), ("srht2", "srht_2", 64)]:
+            if method is None:
+                pre = None
+            else:
+                pre = RandNysPreconditioner(kern, ds, rank, False, 123, method)
+                out[f"{kname}_{ptag}_u"] = pre.u_mat
+                out[f"{kname}_{ptag}_eig"] = pre.eig
+                out[f"{kname}_{ptag}_inv_eig"] = pre.inv_eig
+                out[f"{kname}_{ptag}_ratio"] = np.float64(pre.achieved_ratio)
+                out[f"{kname}_{ptag}_prefactor"] = np.float64(pre.prefactor)
+                out[f"{kname}_{ptag}_zty"] = pre.get_zty()
+                out[f"{kname}_{ptag}_yty"] = np.float64(pre.get_yty())
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False)
+                iters = []
+                for j in range(1, min(niter, 12) + 1):
+                    wj, nj, _ = cg_fit_lib_internal(kern, ds, 1e-30, j, pre, False)
+                    assert nj == j
+                    iters.append(wj)
+            out[f"{kname}_{ptag}_weights"] = w
+            out[f"{kname}_{ptag}_niter"] = np.int64(niter)
+            out[f"{kname}_{ptag}_losses"] = np.asarray(losses)
+            out[f"{kname}_{ptag}_iterates"] = np.stack(iters)
+            print(f"  G7 {kname} {ptag}: niter={niter}")
+    save("g7_cg.npz", **out)
+
+
+# ---------------------------------------------------------------- G8: reference fixture, end to end
+def g8_e2e(xgpr):
+    """tests/fitting_tests/test_cg_fit.py:26-40 on the reference's own 381x84 fixture
+    (tests/test_data/0_block_train{x,y}values.npy): RBF, 4096 RFFs, rank-256 SRHT
+    preconditioner, tol 1e-6 => niter < 10.  The fixture arrays are data files of the
+    reference's test-suite and are stored alongside the expected outputs."""
+    from xGPR import xGPRegression
+    from xGPR.data_handling.dataset_builder import build_regression_dataset
+    xtr = np.load(os.path.join(REF_TESTDATA, "0_block_trainxvalues.npy"))
+    ytr = np.load(os.path.join(REF_TESTDATA, "0_block_trainyvalues.npy"))
+    xte = np.load(os.path.join(REF_TESTDATA, "4_block_testxvalues.npy"))[:64]
+    ds = build_regression_dataset(xtr, ytr, chunk_size=2000)
+    hparam = np.array([np.log(np.sqrt(0.0767)), np.log(0.358)])
+    mod = xGPRegression(num_rffs=4096, kernel_choice="RBF", variance_rffs=12, random_seed=123,
+                        device="cpu", kernel_settings={"intercept": True})
+    mod.set_hyperparams(hparam, ds)
+    pre, ratio = mod.build_preconditioner(ds, max_rank=256, method="srht")
+    niter, losses = mod.fit(ds, preconditioner=pre, max_iter=500, run_diagnostics=True,
+                            tol=1e-6, mode="cg")
+    preds = mod.predict(xte, get_var=False)
+    print(f"  G8: niter={niter} ratio={ratio:.4f}")
+    save("g8_e2e.npz", xtrain=xtr, ytrain=ytr, xtest=xte, hparam_log=hparam,
+         niter=np.int64(niter), losses=np.asarray(losses), weights=np.asarray(mod.weights),
+         ratio=np.float64(ratio), preds=preds, zty=pre.get_zty(), yty=np.float64(pre.get_yty()))
+
+
+if __name__ == "__main__":
+    g1_fht()
+    g2_rbf()
+    g3_conv()
+    g4_maxpool()
+    g5_srht()
+    xgpr = import_reference()
+    g6_draws(xgpr)
+    g7_cg(xgpr)
+    g8_e2e(xgpr)

@@ -1,0 +1,219 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors the REFERENCE produced
+(tests/golden/*.npz, see tests/golden/make_golden.py).  Bar: bit-exact for the native
+ops (same IEEE operations in the same order); parameter draws bit-exact; CG iterates
+1e-9 relative (numpy/BLAS on both sides, only thread-dependent summation order differs).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle as orc
+
+
+def test_g1_fht(oracle):
+    g = load_golden("g1_fht.npz")
+    for P in [2, 4, 32, 1024, 4096]:
+        x32 = g[f"x_{P}"].copy()
+        x64 = x32.astype(np.float64)
+        oracle.cpuFastHadamardTransform2D(x32)
+        oracle.cpuFastHadamardTransform2D(x64)
+        assert np.array_equal(x32, g[f"y32_{P}"])
+        assert np.array_equal(x64, g[f"y64_{P}"])
+    x = g["x3d"].copy()
+    x64 = x.astype(np.float64)
+    oracle.cpuFastHadamardTransform(x)
+    oracle.cpuFastHadamardTransform(x64)
+    assert np.array_equal(x, g["y3d32"])
+    assert np.array_equal(x64, g["y3d64"])
+
+
+def test_fht_matches_hadamard_matrix(oracle):
+    """The reference's own known-answer test: FHT == scipy.linalg.hadamard @ x
+    (reference tests/fht_operations_tests/test_basic_rfgen.py:98-138)."""
+    from scipy.linalg import hadamard
+    rng = np.random.default_rng(123)
+    for P in [2, 8, 64, 512]:
+        x = rng.uniform(-1, 1, size=(7, P))
+        y = x.copy()
+        oracle.cpuFastHadamardTransform2D(y)
+        assert np.allclose(y, x @ hadamard(P).T.astype(np.float64))
+
+
+def test_g2_rbf(oracle):
+    g = load_golden("g2_rbf.npz")
+    for si in range(int(g["n_settings"])):
+        x32, radem, chi32 = g[f"x_{si}"], g[f"radem_{si}"], g[f"chi_{si}"]
+        icpt = bool(g[f"intercept_{si}"])
+        o32 = np.zeros_like(g[f"out32_{si}"])
+        o64 = np.zeros_like(o32)
+        oracle.cpuRBFFeatureGen(x32.copy(), o32, radem, chi32, icpt)
+        oracle.cpuRBFFeatureGen(x32.astype(np.float64), o64, radem, chi32.astype(np.float64), icpt)
+        assert np.array_equal(o32, g[f"out32_{si}"]), si
+        assert np.array_equal(o64, g[f"out64_{si}"]), si
+        if f"sigma_{si}" in g:
+            sigma = float(g[f"sigma_{si}"])
+            for tag, x, c in (("32", x32, chi32),
+                              ("64", x32.astype(np.float64), chi32.astype(np.float64))):
+                o = np.zeros_like(o32)
+                gr = np.zeros(o32.shape + (1,))
+                oracle.cpuRBFGrad(x.copy(), o, gr, radem, c, sigma, icpt)
+                assert np.array_equal(o, g[f"gout{tag}_{si}"])
+                assert np.array_equal(gr, g[f"grad{tag}_{si}"])
+
+
+def test_g3_conv(oracle):
+    g = load_golden("g3_conv.npz")
+    for si in range(int(g["n_settings"])):
+        x32, radem, chi32, sl = g[f"x_{si}"], g[f"radem_{si}"], g[f"chi_{si}"], g[f"seqlen_{si}"]
+        cw, sc = int(g[f"conv_width_{si}"]), int(g[f"scaling_{si}"])
+        o32 = np.zeros_like(g[f"out32_{si}"])
+        o64 = np.zeros_like(o32)
+        oracle.cpuConv1dFGen(x32.copy(), o32, radem, chi32, sl, cw, sc)
+        oracle.cpuConv1dFGen(x32.astype(np.float64), o64, radem, chi32.astype(np.float64), sl, cw, sc)
+        assert np.array_equal(o32, g[f"out32_{si}"]), si
+        assert np.array_equal(o64, g[f"out64_{si}"]), si
+    for tag, dt in (("32", np.float32), ("64", np.float64)):
+        o = np.zeros_like(g["g_out32"])
+        gr = np.zeros_like(g["g_grad32"])
+        oracle.cpuConvGrad(g["g_x"].astype(dt), o, g["g_radem"], g["g_chi"].astype(dt),
+                           g["g_seqlen"], gr, float(g["g_sigma"]), int(g["g_conv_width"]),
+                           int(g["g_scaling"]))
+        assert np.array_equal(o, g[f"g_out{tag}"])
+        assert np.array_equal(gr, g[f"g_grad{tag}"])
+
+
+def test_g4_maxpool(oracle):
+    g = load_golden("g4_maxpool.npz")
+    for si in range(int(g["n_settings"])):
+        x32, radem, chi32, sl = g[f"x_{si}"], g[f"radem_{si}"], g[f"chi_{si}"], g[f"seqlen_{si}"]
+        cw = int(g[f"conv_width_{si}"])
+        o32 = np.zeros_like(g[f"out32_{si}"])
+        o64 = np.zeros_like(o32)
+        oracle.cpuConv1dMaxpool(x32.copy(), o32, radem, chi32, sl, cw)
+        oracle.cpuConv1dMaxpool(x32.astype(np.float64), o64, radem, chi32.astype(np.float64), sl, cw)
+        assert np.array_equal(o32, g[f"out32_{si}"]), si
+        assert np.array_equal(o64, g[f"out64_{si}"]), si
+
+
+def test_g5_srht(oracle):
+    g = load_golden("g5_srht.npz")
+    for P in [256, 512, 2048, 8192, 32768]:
+        x32 = g[f"x_{P}"].copy()
+        x64 = x32.astype(np.float64)
+        oracle.cpuSRHT(x32, g[f"radem_{P}"])
+        oracle.cpuSRHT(x64, g[f"radem_{P}"])
+        assert np.array_equal(x32, g[f"y32_{P}"])
+        assert np.array_equal(x64, g[f"y64_{P}"])
+
+
+def test_g6_draws_bit_exact():
+    """Rademacher / permutation / chi draws must be bit-exact (BASELINE.json north_star)."""
+    g = load_golden("g6_draws.npz")
+    cases = [("cfg1_RBF", 512, 32, None), ("cfg2_RBF", 4096, 256, None),
+             ("cfg3_Matern", 8192, 1024, ("matern", 2.5)), ("cfg3_Cauchy", 8192, 1024, ("cauchy",)),
+             ("cfg5_RBF", 32768, 512, None), ("fix_RBF", 4096, 84, None), ("small_RBF", 64, 3, None)]
+    for tag, rffs, d, extra in cases:
+        radem, chi = orc.draw_sorf_params(rffs, d, 123)
+        if extra and extra[0] == "matern":
+            orc.matern_rescale(chi, extra[1], 123)
+        elif extra and extra[0] == "cauchy":
+            orc.cauchy_rescale(chi, 123)
+        assert radem.dtype == np.int8 and np.array_equal(radem, g[f"{tag}_radem"]), tag
+        assert chi.dtype == np.float32 and np.array_equal(chi, g[f"{tag}_chi"]), tag
+    for tag, rffs, width, nu in [("cfg4_Conv1dRBF", 16384, 9 * 21, None),
+                                 ("graph_GraphRBF", 1024, 12, None),
+                                 ("conv_Conv1dMatern", 2048, 5 * 21, 1.5)]:
+        radem, chi = orc.draw_sorf_params(rffs, width, 123, conv=True)
+        if nu:
+            orc.matern_rescale(chi, nu, 123)
+        assert np.array_equal(radem, g[f"{tag}_radem"]), tag
+        assert np.array_equal(chi, g[f"{tag}_chi"]), tag
+    for tag, rank, m in [("srht_256_4096", 256, 4096), ("srht_512_8192", 512, 8192),
+                         ("srht_64_512", 64, 512), ("srht_100_1000", 100, 1000)]:
+        radem, cs = orc.draw_srht_params(rank, m, 123)
+        assert np.array_equal(radem, g[f"{tag}_radem"])
+        assert np.array_equal(cs, g[f"{tag}_col_sampler"])
+
+
+@pytest.mark.parametrize("kname", ["RBF", "Matern"])
+def test_g7_cg(oracle, kname):
+    g = load_golden("g7_cg.npz")
+    x, y = g["x"].astype(np.float64), g["y"]
+    ds = orc.OracleDataset(x, y, chunk_size=int(g["chunk_size"]))
+    assert np.isclose(ds.y_mean, float(g["y_mean"]), rtol=1e-14)
+    assert np.isclose(ds.y_std, float(g["y_std"]), rtol=1e-14)
+    kern = orc.OracleKernel(kname, int(g["num_rffs"]), x.shape, g["hyperparams"], 123,
+                            matern_nu=2.5, ops=oracle)
+    assert np.array_equal(kern.transform_x(x[:8]), g[f"{kname}_z_first8"])
+    zty, yty = orc.calc_zty(ds, kern)
+    assert np.allclose(zty, g[f"{kname}_zty"], rtol=1e-10, atol=1e-10)
+    assert np.isclose(yty, float(g[f"{kname}_yty"]), rtol=1e-12)
+    for ptag, method in [("none", None), ("srht", "srht"), ("srht2", "srht_2")]:
+        pre = None
+        if method is not None:
+            pre = orc.OracleRandNysPreconditioner(kern, ds, 64, 123, method)
+            assert np.allclose(pre.eig, g[f"{kname}_{ptag}_eig"], rtol=1e-7)
+            assert np.isclose(pre.achieved_ratio, float(g[f"{kname}_{ptag}_ratio"]), rtol=1e-6)
+            assert np.allclose(pre.get_zty(), g[f"{kname}_{ptag}_zty"], rtol=1e-10, atol=1e-10)
+            # U is defined up to the sign of each column: compare the projector
+            u_ref = g[f"{kname}_{ptag}_u"]
+            v = np.linspace(-1, 1, u_ref.shape[0])
+            assert np.allclose(pre.u_mat @ (pre.u_mat.T @ v), u_ref @ (u_ref.T @ v), atol=1e-8)
+        w, niter, losses, _ = orc.cg_fit_lib_internal(kern, ds, 1e-8, 500, pre)
+        assert niter == int(g[f"{kname}_{ptag}_niter"])
+        wref = g[f"{kname}_{ptag}_weights"]
+        assert np.linalg.norm(w - wref) <= 1e-7 * np.linalg.norm(wref)
+        trace = {}
+        nit = g[f"{kname}_{ptag}_iterates"].shape[0]
+        orc.cg_fit_lib_internal(kern, ds, 1e-30, nit, pre, trace=trace)
+        n = ds.get_ndatapoints()
+        for j in range(nit):
+            ref = g[f"{kname}_{ptag}_iterates"][j]
+            got = trace["x_k"][j][:, 0] * n
+            assert np.linalg.norm(got - ref) <= 1e-9 * np.linalg.norm(ref), (ptag, j)
+        assert np.allclose(losses, g[f"{kname}_{ptag}_losses"], rtol=1e-6)
+
+
+def test_g8_reference_fixture(oracle):
+    """Reference tests/fitting_tests/test_cg_fit.py:26-40: rank-256 SRHT preconditioner on the
+    381x84 fixture with 4096 RFFs, tol 1e-6 => niter < 10 (reference got 7)."""
+    g = load_golden("g8_e2e.npz")
+    x, y = g["xtrain"], g["ytrain"]
+    ds = orc.OracleDataset(x, y, chunk_size=2000)
+    kern = orc.OracleKernel("RBF", 4096, x.shape, np.exp(g["hparam_log"]), 123, ops=oracle)
+    pre = orc.OracleRandNysPreconditioner(kern, ds, 256, 123, "srht")
+    assert np.isclose(pre.achieved_ratio, float(g["ratio"]), rtol=1e-6)
+    w, niter, losses, conv = orc.cg_fit_lib_internal(kern, ds, 1e-6, 500, pre)
+    assert conv and niter == int(g["niter"]) and niter < 10
+    assert np.linalg.norm(w - g["weights"]) <= 1e-7 * np.linalg.norm(g["weights"])
+    z = kern.transform_x(g["xtest"])
+    preds = (z @ w) * ds.y_std + ds.y_mean
+    assert np.allclose(preds, g["preds"], rtol=1e-7, atol=1e-9)
+
+
+def test_oracle_validation_errors(oracle):
+    """The ops raise RuntimeError where the reference throws (rbf_ops.cpp:49-62,
+    rbf_convolution.cpp:49-82; reference tests/fht_operations_tests/
+    test_variable_length_seq_handling.py:74-95)."""
+    radem, chi = orc.draw_sorf_params(64, 10, 123)
+    x = np.zeros((4, 10), np.float32)
+    with pytest.raises(RuntimeError):
+        oracle.cpuRBFFeatureGen(x, np.zeros((3, 64)), radem, chi, False)
+    with pytest.raises(RuntimeError):
+        oracle.cpuRBFFeatureGen(x, np.zeros((4, 62)), radem, chi, False)
+    with pytest.raises(RuntimeError):
+        oracle.cpuRBFFeatureGen(np.zeros((0, 10), np.float32), np.zeros((0, 64)), radem, chi, False)
+    radem, chi = orc.draw_sorf_params(64, 3 * 4, 123, conv=True)
+    xc = np.zeros((3, 10, 4), np.float32)
+    good = np.array([10, 5, 3], np.int32)
+    oracle.cpuConv1dFGen(xc, np.zeros((3, 64)), radem, chi, good, 3, 0)
+    for bad in (np.array([11, 5, 3], np.int32), np.array([10, 5, 2], np.int32),
+                np.array([10, 5], np.int32)):
+        with pytest.raises(RuntimeError):
+            oracle.cpuConv1dFGen(xc, np.zeros((3, 64)), radem, chi, bad, 3, 0)
+    with pytest.raises(RuntimeError):
+        oracle.cpuConv1dFGen(xc, np.zeros((3, 64)), radem, chi, good, 11, 0)
+    with pytest.raises(RuntimeError):
+        oracle.cpuFastHadamardTransform2D(np.zeros((3, 12)))
+    with pytest.raises(RuntimeError):
+        oracle.cpuSRHT(np.zeros((3, 16)), np.ones(8, np.int8))
