@@ -1,0 +1,168 @@
+/* xgpr_hip.h -- C ABI of libxgpr_hip.so, the MI355X (gfx950) implementation of the
+ * xGPR random-feature / CG hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one operator of the
+ * reference's GPU extension module
+ *     src/xGPR/random_feature_generation/gpu_rf_gen/xgpr_cuda_rfgen_cpp_ext.cpp:20-93
+ * (or the CPU twin cpu_rf_gen/xgpr_cpu_rfgen_cpp_ext.cpp:23-147 where the CUDA module
+ * has no counterpart), or one per-chunk step of the reference's CG / preconditioner
+ * loops that this library fuses with feature generation.  Citations are relative to
+ * /root/reference/.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no framework types; `stream` is a hipStream_t passed as
+ *     void* (NULL = the null stream).  Every call is asynchronous and stream-ordered.
+ *   - all array arguments are DEVICE pointers to C-contiguous data unless the name ends
+ *     in `_host`.  Nothing is retained after return; nothing is allocated (scratch comes
+ *     in through `workspace`, sized by the matching *_workspace_bytes() function).
+ *   - return value: 0 on success, a negative code otherwise; xgpr_last_error() returns
+ *     the message the reference would have thrown as std::runtime_error (thread-local).
+ *   - "_f32"/"_f64" is the element type T of (input, chi) -- the reference overloads each
+ *     operator for float and double (e.g. xgpr_cuda_rfgen_cpp_ext.cpp:32-40).
+ */
+#ifndef XGPR_HIP_H
+#define XGPR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes (messages mirror the reference's throw sites) */
+#define XGPR_OK                 0
+#define XGPR_ERR_NO_DATAPOINTS (-1)  /* rbf_ops.cpp:49-50   "no datapoints" */
+#define XGPR_ERR_ODD_OUTPUT    (-2)  /* rbf_ops.cpp:51-52   "last dim of output must be even number" */
+#define XGPR_ERR_RFFS_FREQS    (-3)  /* rbf_ops.cpp:53-54,61-62 "incorrect number of rffs and or freqs." */
+#define XGPR_ERR_ARRAY_SIZES   (-4)  /* rbf_ops.cpp:168-170 "Wrong array sizes." */
+#define XGPR_ERR_SEQLEN_SIZE   (-5)  /* rbf_convolution.cpp:55-56 "wrong array sizes" */
+#define XGPR_ERR_CONV_WIDTH    (-6)  /* rbf_convolution.cpp:57-58 "invalid conv_width" */
+#define XGPR_ERR_SEQLEN_RANGE  (-7)  /* rbf_convolution.cpp:78-82 "All sequence lengths must be >= conv width and < array size." */
+#define XGPR_ERR_ARRAY_DIMS    (-8)  /* transform_functions.cpp:109-110 "incorrect array dims passed" */
+#define XGPR_ERR_NOT_POW2      (-9)  /* transform_functions.cpp:111-114 "last dim not power of 2 > 1" */
+#define XGPR_ERR_UNSUPPORTED   (-20) /* shape outside what this build supports (message says which) */
+#define XGPR_ERR_WORKSPACE     (-21) /* workspace missing / too small / misaligned pointer */
+#define XGPR_ERR_HIP           (-100)/* a HIP runtime call or kernel launch failed */
+
+const char *xgpr_last_error(void);
+/* "gfx950" etc: the offload architecture the device code was built for. */
+const char *xgpr_build_arch(void);
+
+/* ---- bare FHT: cudaFastHadamardTransform2D (xgpr_cuda_rfgen_cpp_ext.cpp:21-24) and the
+ * CPU-only 3-D form cpuFastHadamardTransform (xgpr_cpu_rfgen_cpp_ext.cpp:24-30).
+ * In place, un-normalised, over the last axis of x[n, dim1, dim2] (dim1 = 1 for 2-D). */
+int xgpr_fht_f32(float *x, long n, long dim1, long dim2, void *stream);
+int xgpr_fht_f64(double *x, long n, long dim1, long dim2, void *stream);
+
+/* ---- cudaSRHT (xgpr_cuda_rfgen_cpp_ext.cpp:25-30): x[n, dim] <- FHT(x * radem * 2^(-log2(dim)/2)) */
+int xgpr_srht_f32(float *x, const int8_t *radem, long n, long dim, long radem_len, void *stream);
+int xgpr_srht_f64(double *x, const int8_t *radem, long n, long dim, long radem_len, void *stream);
+
+/* ---- cudaRBFFeatureGen (xgpr_cuda_rfgen_cpp_ext.cpp:32-40)
+ * x[n, d] (T), out[out_rows, num_rffs] (f64), radem[3, 1, radem_shape2] (int8),
+ * chi[num_freqs] (T).  Like the reference's CUDA kernel (rbf_ops.cu:121-127) the output
+ * is OVERWRITTEN: out[i, 2f] = s*cos(chi[f]*sorf(x_i)[f]), out[i, 2f+1] = s*sin(...). */
+size_t xgpr_rbf_workspace_bytes(long radem_shape2);
+int xgpr_rbf_feature_gen_f32(const float *x, double *out, const int8_t *radem, const float *chi,
+                             long n, long d, long out_rows, long num_rffs, long num_freqs,
+                             long radem_shape2, int fit_intercept,
+                             void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_rbf_feature_gen_f64(const double *x, double *out, const int8_t *radem, const double *chi,
+                             long n, long d, long out_rows, long num_rffs, long num_freqs,
+                             long radem_shape2, int fit_intercept,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- cudaRBFGrad (xgpr_cuda_rfgen_cpp_ext.cpp:41-49): features + d/dsigma.
+ * grad[grad_rows, grad_cols, 1] (f64).  x is NOT pre-multiplied by sigma.  sigma is a
+ * double as in the CPU module (cpu_rf_gen/rbf_ops/rbf_ops.h:57). */
+int xgpr_rbf_grad_f32(const float *x, double *out, double *grad, const int8_t *radem,
+                      const float *chi, long n, long d, long out_rows, long num_rffs,
+                      long grad_rows, long grad_cols, long num_freqs, long radem_shape2,
+                      double sigma, int fit_intercept,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_rbf_grad_f64(const double *x, double *out, double *grad, const int8_t *radem,
+                      const double *chi, long n, long d, long out_rows, long num_rffs,
+                      long grad_rows, long grad_cols, long num_freqs, long radem_shape2,
+                      double sigma, int fit_intercept,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- cudaConv1dFGen (xgpr_cuda_rfgen_cpp_ext.cpp:70-80): x[n, L, C]; k-mer windows of
+ * conv_width*C contiguous elements; results are ADDED into out (which callers zero), as in
+ * the reference (rbf_convolution.cu:140-146).  scaling_type 0 none / 1 sqrt / 2 full.
+ * seqlen_host[nseq]: int32 on the HOST, as in the reference's CUDA module
+ * (gpu_rf_gen/convolution_ops/rbf_convolution.h:19) -- validated there; seqlen_dev is the
+ * same array on the device (the reference H2D-copies it on every call,
+ * rbf_convolution.cu:368-379; here the caller owns that copy). */
+int xgpr_conv1d_fgen_f32(const float *x, double *out, const int8_t *radem, const float *chi,
+                         const int32_t *seqlen_host, const int32_t *seqlen_dev,
+                         long n, long L, long C, long out_rows, long num_rffs, long num_freqs,
+                         long radem_shape2, long nseq, int conv_width, int scaling_type,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_conv1d_fgen_f64(const double *x, double *out, const int8_t *radem, const double *chi,
+                         const int32_t *seqlen_host, const int32_t *seqlen_dev,
+                         long n, long L, long C, long out_rows, long num_rffs, long num_freqs,
+                         long radem_shape2, long nseq, int conv_width, int scaling_type,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- cudaConvGrad (xgpr_cuda_rfgen_cpp_ext.cpp:81-92) */
+int xgpr_conv_grad_f32(const float *x, double *out, double *grad, const int8_t *radem,
+                       const float *chi, const int32_t *seqlen_host, const int32_t *seqlen_dev,
+                       long n, long L, long C, long out_rows, long num_rffs, long grad_rows,
+                       long grad_cols, long num_freqs, long radem_shape2, long nseq,
+                       double sigma, int conv_width, int scaling_type,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_conv_grad_f64(const double *x, double *out, double *grad, const int8_t *radem,
+                       const double *chi, const int32_t *seqlen_host, const int32_t *seqlen_dev,
+                       long n, long L, long C, long out_rows, long num_rffs, long grad_rows,
+                       long grad_cols, long num_freqs, long radem_shape2, long nseq,
+                       double sigma, int conv_width, int scaling_type,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- cudaConv1dMaxpool (xgpr_cuda_rfgen_cpp_ext.cpp:61-69): out[n, num_rffs] float32,
+ * out = max(out, chi * sorf(window)) over k-mers; num_freqs == num_rffs;
+ * radem_shape2 == reps * P exactly (conv1d_operations.cpp:65-68). */
+int xgpr_conv1d_maxpool_f32(const float *x, float *out, const int8_t *radem, const float *chi,
+                            const int32_t *seqlen_host, const int32_t *seqlen_dev,
+                            long n, long L, long C, long out_rows, long num_rffs, long num_freqs,
+                            long radem_shape2, long nseq, int conv_width,
+                            void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_conv1d_maxpool_f64(const double *x, float *out, const int8_t *radem, const double *chi,
+                            const int32_t *seqlen_host, const int32_t *seqlen_dev,
+                            long n, long L, long C, long out_rows, long num_rffs, long num_freqs,
+                            long radem_shape2, long nseq, int conv_width,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- fused CG matvec: the per-chunk body of CPU/GPU_ConjugateGrad._matvec
+ * (src/xGPR/fitting_toolkit/cg_tools.py:173-200 / :26-53) for one shard of rows,
+ *     w_out[m] = sum_i Z[i, m] * (Z[i, :] . v),   Z = transform_x(x)  (never written to HBM),
+ * i.e. `for chunk: Z = kernel.transform_x(x); matvec += Z.T @ (Z @ vec)` with feature
+ * generation (kernel_baseclass.py:269-299, incl. the intercept column Z[:,0] = 1) fused in.
+ * x[n, d] float32 ALREADY multiplied by sigma (sorf_kernel_baseclass.py:117); v, w_out
+ * [num_rffs] f64.  lambda^2 * v is NOT added (the caller adds it after the all-reduce).
+ * Deterministic: per-workgroup partial sums are combined in a fixed order.
+ * Supported: padded width P = 2^ceil(log2(max(d,2))) <= 1024, num_freqs <= 8192. */
+size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2);
+int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v,
+                        double *w_out, long n, long d, long num_rffs, long num_freqs,
+                        long radem_shape2, int fit_intercept,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- z^T y for one shard (scoring_toolkit/exact_nmll_calcs.py:13-39 calc_zty, and the
+ * `zty += Z.T @ y` line of rand_nys_constructors.py:96-123), fused with feature
+ * generation: zty_out[m] = sum_i Z[i, m] * y[i].  Same support envelope as the matvec. */
+int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const double *y,
+                 double *zty_out, long n, long d, long num_rffs, long num_freqs,
+                 long radem_shape2, int fit_intercept,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- self test of the cross-lane butterfly stages the wave-level FHT is built on: for each
+ * of the 6 lane strides h = 1, 2, 4, 8, 16, 32 runs one stage on v[r] = lane + 64 r
+ * (r = 0..15) and writes the result to out[6][16][64] (int32, device).  Expected:
+ * bit h of lane clear -> 2 lane + h + 128 r, set -> -h. */
+int xgpr_selftest_lane_xor(int32_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XGPR_HIP_H */

@@ -1,0 +1,272 @@
+"""GPU parity tests of the native operators (through the C ABI, via the reference's own
+operator surface xgpr_amd.xgpr_hip_rfgen_ext) against the golden vectors the reference
+produced and against the CPU oracle on seeded inputs.
+
+Bars
+  * FHT / SRHT / max-pool: bit-exact (adds, subtracts and single multiplies in the
+    reference's order).
+  * cos/sin features, float path: the f32 argument of every cos/sin is bit-identical to
+    the reference's; device sincos is <= 1.6 ulp, glibc's < 1 ulp, so
+    |gpu - ref| <= 4e-7 * scale elementwise (scale = sqrt(1/F)); the north-star bar
+    (1e-5 relative) is asserted as allclose(rtol=1e-5, atol=1e-5*scale).
+  * double path: 1e-13 * scale (ocml vs glibc sin/cos in double).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from xgpr_amd import xgpr_hip_rfgen_ext as e
+    return e
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def check_features(got, ref, scale, double=False):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    tight = 1e-13 if double else 4e-7
+    err = np.abs(got - ref).max()
+    assert err <= tight * scale, f"max abs err {err:.3e} vs {tight * scale:.3e}"
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_selftest_cross_lane(ext):
+    out = ext.selftest_lane_xor(DEV)
+    lane = np.arange(64)
+    for q, h in enumerate([1, 2, 4, 8, 16, 32]):
+        for r in range(16):
+            exp = np.where(lane & h, -h, 2 * lane + h + 128 * r)
+            assert np.array_equal(out[q, r], exp), (h, r, out[q, r])
+
+
+def test_g1_fht_bit_exact(ext):
+    g = load_golden("g1_fht.npz")
+    for P in [2, 4, 32, 1024, 4096]:
+        x32 = dev(g[f"x_{P}"])
+        x64 = dev(g[f"x_{P}"].astype(np.float64))
+        ext.hipFastHadamardTransform2D(x32)
+        ext.hipFastHadamardTransform2D(x64)
+        assert np.array_equal(x32.cpu().numpy(), g[f"y32_{P}"]), P
+        assert np.array_equal(x64.cpu().numpy(), g[f"y64_{P}"]), P
+    x = dev(g["x3d"])
+    x64 = dev(g["x3d"].astype(np.float64))
+    ext.hipFastHadamardTransform(x)
+    ext.hipFastHadamardTransform(x64)
+    assert np.array_equal(x.cpu().numpy(), g["y3d32"])
+    assert np.array_equal(x64.cpu().numpy(), g["y3d64"])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,P", [(3, 8), (37, 64), (5, 512), (3, 16384), (2, 32768), (2, 65536), (1, 131072)])
+def test_fht_vs_oracle(ext, oracle, dtype, n, P):
+    rng = np.random.default_rng(P + n)
+    x = rng.standard_normal((n, P)).astype(dtype)
+    ref = x.copy()
+    oracle.cpuFastHadamardTransform2D(ref)
+    xd = dev(x)
+    ext.hipFastHadamardTransform2D(xd)
+    assert np.array_equal(xd.cpu().numpy(), ref)
+    radem = rng.choice(np.asarray([-1, 1], np.int8), size=P)
+    ref = x.copy()
+    oracle.cpuSRHT(ref, radem)
+    xd = dev(x)
+    ext.hipSRHT(xd, dev(radem))
+    assert np.array_equal(xd.cpu().numpy(), ref)
+
+
+def test_g5_srht_bit_exact(ext):
+    g = load_golden("g5_srht.npz")
+    for P in [256, 512, 2048, 8192, 32768]:
+        x32 = dev(g[f"x_{P}"])
+        x64 = dev(g[f"x_{P}"].astype(np.float64))
+        r = dev(g[f"radem_{P}"])
+        ext.hipSRHT(x32, r)
+        ext.hipSRHT(x64, r)
+        assert np.array_equal(x32.cpu().numpy(), g[f"y32_{P}"]), P
+        assert np.array_equal(x64.cpu().numpy(), g[f"y64_{P}"]), P
+
+
+def test_g2_rbf_golden(ext):
+    g = load_golden("g2_rbf.npz")
+    for si in range(int(g["n_settings"])):
+        x32, radem, chi32 = g[f"x_{si}"], g[f"radem_{si}"], g[f"chi_{si}"]
+        icpt = bool(g[f"intercept_{si}"])
+        F = chi32.shape[0]
+        scale = np.sqrt(1.0 / (F - 0.5 if icpt else F))
+        o32 = torch.zeros(g[f"out32_{si}"].shape, dtype=torch.float64, device=DEV)
+        o64 = torch.zeros_like(o32)
+        ext.hipRBFFeatureGen(dev(x32), o32, dev(radem), dev(chi32), icpt)
+        ext.hipRBFFeatureGen(dev(x32.astype(np.float64)), o64, dev(radem), dev(chi32.astype(np.float64)), icpt)
+        check_features(o32, g[f"out32_{si}"], scale)
+        check_features(o64, g[f"out64_{si}"], scale, double=True)
+        if f"sigma_{si}" in g:
+            sigma = float(g[f"sigma_{si}"])
+            for tag, dt in (("32", np.float32), ("64", np.float64)):
+                o = torch.zeros_like(o32)
+                gr = torch.zeros(o32.shape + (1,), dtype=torch.float64, device=DEV)
+                ext.hipRBFGrad(dev(x32.astype(dt)), o, gr, dev(radem), dev(chi32.astype(dt)), sigma, icpt)
+                check_features(o, g[f"gout{tag}_{si}"], scale, double=False)
+                gref = g[f"grad{tag}_{si}"]
+                gs = np.abs(gref).max()
+                assert np.abs(gr.cpu().numpy() - gref).max() <= 1e-5 * gs
+
+
+@pytest.mark.parametrize("d,rffs,icpt,n", [
+    (2, 16, False, 9), (3, 64, True, 33), (7, 512, False, 17), (16, 100, True, 5), (32, 512, True, 200),
+    (50, 128, False, 11), (64, 2048, True, 9), (100, 300, False, 13), (128, 4096, True, 7),
+    (256, 4096, True, 300), (300, 1000, False, 6), (512, 16384, False, 3), (513, 4096, True, 5),
+    (1000, 8192, True, 4), (1024, 8192, True, 64), (1024, 2050, False, 3), (1025, 4096, True, 3),
+    (2003, 4000, False, 3)])
+def test_rbf_vs_oracle(ext, oracle, d, rffs, icpt, n):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(d * 7 + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, d, 321)
+    x = (rng.standard_normal((n, d)) * 2.0).astype(np.float32)
+    ref = np.zeros((n, rffs))
+    oracle.cpuRBFFeatureGen(x.copy(), ref, radem, chi, icpt)
+    out = torch.full((n, rffs), 7.0, dtype=torch.float64, device=DEV)   # overwritten, not accumulated
+    ext.hipRBFFeatureGen(dev(x), out, dev(radem), dev(chi), icpt)
+    F = rffs // 2
+    check_features(out, ref, np.sqrt(1.0 / (F - 0.5 if icpt else F)))
+
+
+def test_rbf_deterministic(ext):
+    from oracle import oracle as orc
+    radem, chi = orc.draw_sorf_params(8192, 1024, 123)
+    x = torch.randn(128, 1024, device=DEV, dtype=torch.float32)
+    a = torch.zeros(128, 8192, dtype=torch.float64, device=DEV)
+    b = torch.zeros_like(a)
+    ext.hipRBFFeatureGen(x, a, dev(radem), dev(chi), True)
+    ext.hipRBFFeatureGen(x, b, dev(radem), dev(chi), True)
+    assert torch.equal(a, b)
+
+
+def test_g3_conv_golden(ext):
+    g = load_golden("g3_conv.npz")
+    for si in range(int(g["n_settings"])):
+        x32, radem, chi32, sl = g[f"x_{si}"], g[f"radem_{si}"], g[f"chi_{si}"], g[f"seqlen_{si}"]
+        cw, sc = int(g[f"conv_width_{si}"]), int(g[f"scaling_{si}"])
+        F = chi32.shape[0]
+        kmax = int(sl.max()) - cw + 1
+        scale = np.sqrt(1.0 / F) * {0: kmax, 1: np.sqrt(kmax), 2: 1.0}[sc]   # sum of up to kmax terms
+        o32 = torch.zeros(g[f"out32_{si}"].shape, dtype=torch.float64, device=DEV)
+        o64 = torch.zeros_like(o32)
+        ext.hipConv1dFGen(dev(x32), o32, dev(radem), dev(chi32), sl, cw, sc)
+        ext.hipConv1dFGen(dev(x32.astype(np.float64)), o64, dev(radem), dev(chi32.astype(np.float64)), sl, cw, sc)
+        check_features(o32, g[f"out32_{si}"], scale)
+        check_features(o64, g[f"out64_{si}"], scale, double=True)
+    for tag, dt in (("32", np.float32), ("64", np.float64)):
+        o = torch.zeros(g["g_out32"].shape, dtype=torch.float64, device=DEV)
+        gr = torch.zeros(g["g_grad32"].shape, dtype=torch.float64, device=DEV)
+        ext.hipConvGrad(dev(g["g_x"].astype(dt)), o, dev(g["g_radem"]), dev(g["g_chi"].astype(dt)),
+                        g["g_seqlen"], gr, float(g["g_sigma"]), int(g["g_conv_width"]), int(g["g_scaling"]))
+        ref_o, ref_g = g[f"g_out{tag}"], g[f"g_grad{tag}"]
+        assert np.abs(o.cpu().numpy() - ref_o).max() <= 1e-5 * np.abs(ref_o).max()
+        assert np.abs(gr.cpu().numpy() - ref_g).max() <= 1e-5 * np.abs(ref_g).max()
+
+
+@pytest.mark.parametrize("L,C,cw,rffs,sc,n", [(30, 21, 9, 1024, 0, 9), (17, 4, 1, 64, 1, 21), (40, 21, 5, 600, 2, 7),
+                                              (64, 21, 9, 4096, 1, 6), (12, 300, 4, 512, 1, 4), (25, 8, 3, 2050, 0, 5)])
+def test_conv_vs_oracle(ext, oracle, L, C, cw, rffs, sc, n):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(L * C + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, cw * C, 77, conv=True)
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(cw, L + 1, size=n).astype(np.int32)
+    ref = np.zeros((n, rffs))
+    oracle.cpuConv1dFGen(x, ref, radem, chi, sl, cw, sc)
+    out = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+    ext.hipConv1dFGen(dev(x), out, dev(radem), dev(chi), sl, cw, sc)
+    kmax = int(sl.max()) - cw + 1
+    scale = np.sqrt(2.0 / rffs) * {0: kmax, 1: np.sqrt(kmax), 2: 1.0}[sc]
+    check_features(out, ref, scale)
+    # accumulate semantics: a second call adds on top (reference rbf_convolution.cu:140-146)
+    ext.hipConv1dFGen(dev(x), out, dev(radem), dev(chi), sl, cw, sc)
+    check_features(out, 2 * ref, 2 * scale)
+
+
+def test_g4_maxpool_bit_exact(ext):
+    g = load_golden("g4_maxpool.npz")
+    for si in range(int(g["n_settings"])):
+        x32, radem, chi32, sl = g[f"x_{si}"], g[f"radem_{si}"], g[f"chi_{si}"], g[f"seqlen_{si}"]
+        cw = int(g[f"conv_width_{si}"])
+        o32 = torch.zeros(g[f"out32_{si}"].shape, dtype=torch.float32, device=DEV)
+        o64 = torch.zeros_like(o32)
+        ext.hipConv1dMaxpool(dev(x32), o32, dev(radem), dev(chi32), sl, cw)
+        ext.hipConv1dMaxpool(dev(x32.astype(np.float64)), o64, dev(radem), dev(chi32.astype(np.float64)), sl, cw)
+        assert np.array_equal(o32.cpu().numpy(), g[f"out32_{si}"]), si
+        assert np.array_equal(o64.cpu().numpy(), g[f"out64_{si}"]), si
+
+
+def test_error_behaviour(ext):
+    """RuntimeError where the reference throws; TypeError for un-converted arguments
+    (nanobind .noconvert()); reference tests/fht_operations_tests/
+    test_variable_length_seq_handling.py:74-95."""
+    from oracle import oracle as orc
+    radem, chi = orc.draw_sorf_params(64, 10, 123)
+    x = torch.zeros(4, 10, device=DEV)
+    with pytest.raises(RuntimeError):
+        ext.hipRBFFeatureGen(x, torch.zeros(3, 64, dtype=torch.float64, device=DEV), dev(radem), dev(chi), False)
+    with pytest.raises(RuntimeError):
+        ext.hipRBFFeatureGen(x, torch.zeros(4, 62, dtype=torch.float64, device=DEV), dev(radem), dev(chi), False)
+    with pytest.raises(TypeError):
+        ext.hipRBFFeatureGen(x, torch.zeros(4, 64, dtype=torch.float32, device=DEV), dev(radem), dev(chi), False)
+    with pytest.raises(TypeError):
+        ext.hipRBFFeatureGen(x.cpu(), torch.zeros(4, 64, dtype=torch.float64, device=DEV), dev(radem), dev(chi), False)
+    with pytest.raises(TypeError):
+        ext.hipRBFFeatureGen(x.double(), torch.zeros(4, 64, dtype=torch.float64, device=DEV), dev(radem), dev(chi), False)
+    radem, chi = orc.draw_sorf_params(64, 12, 123, conv=True)
+    xc = torch.zeros(3, 10, 4, device=DEV)
+    out = torch.zeros(3, 64, dtype=torch.float64, device=DEV)
+    ext.hipConv1dFGen(xc, out, dev(radem), dev(chi), np.array([10, 5, 3], np.int32), 3, 0)
+    for bad in (np.array([11, 5, 3], np.int32), np.array([10, 5, 2], np.int32), np.array([10, 5], np.int32)):
+        with pytest.raises(RuntimeError):
+            ext.hipConv1dFGen(xc, out, dev(radem), dev(chi), bad, 3, 0)
+    with pytest.raises(RuntimeError):
+        ext.hipConv1dFGen(xc, out, dev(radem), dev(chi), np.array([10, 5, 3], np.int32), 11, 0)
+    with pytest.raises(TypeError):
+        ext.hipConv1dFGen(xc, out, dev(radem), dev(chi), np.array([10, 5, 3], np.int64), 3, 0)
+    with pytest.raises(RuntimeError):
+        ext.hipFastHadamardTransform2D(torch.zeros(3, 12, device=DEV))
+    with pytest.raises(RuntimeError):
+        ext.hipSRHT(torch.zeros(3, 16, device=DEV), torch.ones(8, dtype=torch.int8, device=DEV))
+
+
+@pytest.mark.parametrize("d,rffs,icpt,n", [(32, 512, True, 2000), (20, 64, False, 100), (256, 4096, True, 3000),
+                                           (100, 3000, True, 777), (1024, 8192, True, 1500),
+                                           (512, 16384, False, 300), (8, 2048, True, 50)])
+def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
+    """hipZtZMatvec == Z.T @ (Z @ v) with Z = transform_x(x) from the oracle (incl. Z[:,0] = 1);
+    f64 accumulation, so 1e-9 relative in the max norm; and bit-reproducible run to run."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(d + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, d, 11)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    z = np.zeros((n, rffs))
+    oracle.cpuRBFFeatureGen(x.copy(), z, radem, chi, icpt)
+    if icpt:
+        z[:, 0] = 1.0
+    v = rng.standard_normal(rffs)
+    y = rng.standard_normal(n)
+    ref = z.T @ (z @ v)
+    out = torch.zeros(rffs, dtype=torch.float64, device=DEV)
+    ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), dev(v), out, icpt)
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+    out2 = torch.zeros_like(out)
+    ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), dev(v), out2, icpt)
+    assert torch.equal(out, out2)
+    zty = torch.zeros(rffs, dtype=torch.float64, device=DEV)
+    ext.hipZtY(dev(x), dev(radem), dev(chi), dev(y), zty, icpt)
+    refy = z.T @ y
+    assert np.abs(zty.cpu().numpy() - refy).max() <= 1e-6 * np.abs(refy).max()

@@ -1,0 +1,80 @@
+"""ctypes binding of libxgpr_hip.so (the C ABI declared in include/xgpr_hip.h).
+
+There is no CPU fallback: if the library is missing the import of any product module
+fails loudly, and every compute entry point needs a HIP device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxgpr_hip.so")
+
+_vp, _l, _i, _d, _sz = C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_size_t
+
+# name -> argtypes; mirrors include/xgpr_hip.h one to one (tests/test_cabi.py checks that
+# every function declared in the header is listed here and exported by the library).
+SIGNATURES = {
+    "xgpr_fht_f32": [_vp, _l, _l, _l, _vp],
+    "xgpr_fht_f64": [_vp, _l, _l, _l, _vp],
+    "xgpr_srht_f32": [_vp, _vp, _l, _l, _l, _vp],
+    "xgpr_srht_f64": [_vp, _vp, _l, _l, _l, _vp],
+    "xgpr_rbf_feature_gen_f32": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_rbf_feature_gen_f64": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_rbf_grad_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _vp, _sz, _vp],
+    "xgpr_rbf_grad_f64": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _vp, _sz, _vp],
+    "xgpr_conv1d_fgen_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _i, _vp, _sz, _vp],
+    "xgpr_conv1d_fgen_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _i, _vp, _sz, _vp],
+    "xgpr_conv_grad_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _i,
+                           _vp, _sz, _vp],
+    "xgpr_conv_grad_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _i,
+                           _vp, _sz, _vp],
+    "xgpr_conv1d_maxpool_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_conv1d_maxpool_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_ztz_matvec_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_zty_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_selftest_lane_xor": [_vp, _vp],
+}
+SIZE_FUNCS = {
+    "xgpr_rbf_workspace_bytes": [_l],
+    "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
+}
+STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch"]
+
+_lib = None
+
+
+def load():
+    """Load libxgpr_hip.so.  Raises ImportError (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -m xgpr_amd.build`); xgpr_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, args in SIZE_FUNCS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_size_t
+    for name in STRING_FUNCS:
+        fn = getattr(lib, name)
+        fn.argtypes = []
+        fn.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().xgpr_last_error().decode()
+
+
+def check(rc):
+    """Map a negative return code to the RuntimeError the reference would have thrown."""
+    if rc != 0:
+        raise RuntimeError(last_error() or f"xgpr_hip error {rc}")
+    return 0

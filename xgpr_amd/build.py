@@ -1,0 +1,51 @@
+"""Builds libxgpr_hip.so (the C-ABI library with the gfx950 kernels) in-tree with hipcc.
+
+    python -m xgpr_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the authoring container;
+the built .so travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "xgpr_hip.hip")
+HDR = os.path.join(HERE, "..", "include", "xgpr_hip.h")
+LIB = os.path.join(HERE, "libxgpr_hip.so")
+
+# -ffp-contract=off: the butterflies / Rademacher multiplies must round like the reference's
+# scalar code (see the header comment of csrc/xgpr_hip.hip).
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libxgpr_hip.so")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in (SRC, HDR))
+
+
+def build_extension(force=False, verbose=False):
+    """Compile csrc/xgpr_hip.hip -> libxgpr_hip.so if missing or older than its sources."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path()] + FLAGS + [SRC, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_extension(force="--force" in sys.argv, verbose=True))

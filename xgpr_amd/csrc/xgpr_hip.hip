@@ -1,0 +1,1118 @@
+// xgpr_hip.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI for the xGPR hot path:
+// SORF / fast-Hadamard random-feature generation and the fused Z^T(Zv) CG matvec.
+//
+// Written for wave64 CDNA4 only (no CUDA/portability layer).  Build:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared xgpr_hip.hip -o libxgpr_hip.so
+// -ffp-contract=off is REQUIRED: the butterflies and the Rademacher/normaliser multiplies
+// must round exactly like the reference's scalar C++ (which is built without FMA), so that
+// the f32 argument of every cos/sin is bit-identical to the reference's.  Places where a
+// fused multiply-add is wanted call __builtin_fma[f] explicitly.
+//
+// Reference behaviour restated here (paths relative to /root/reference/src/xGPR/):
+//   FHT butterflies      random_feature_generation/cpu_rf_gen/shared_fht_functions/hadamard_transforms.cpp:83-127
+//   SORF (3 x D,H)       .../shared_fht_functions/shared_rfgen_ops.cpp:51-78
+//   RBF post-process     .../shared_fht_functions/shared_rfgen_ops.cpp:92-114 (grad :125-156)
+//   row drivers          .../rbf_ops/rbf_ops.cpp:27-106, convolution_ops/rbf_convolution.cpp:23-140,
+//                        convolution_ops/conv1d_operations.cpp:23-168, basic_ops/transform_functions.cpp:22-121
+//   CG matvec            fitting_toolkit/cg_tools.py:173-200 ; z^T y  scoring_toolkit/exact_nmll_calcs.py:13-39
+//
+// Layout of one wave's data ("wave tile"): 16 VGPRs x 64 lanes = 1024 consecutive random
+// frequencies of one datapoint; register r, lane l holds frequency  f = 1024*b + 64*r + l.
+// For padded width P <= 1024 that is 1024/P complete SORF transforms; within a transform the
+// element index is (64*r + l) mod P, so butterfly strides < 64 are cross-lane (DPP /
+// v_permlane{16,32}_swap, no LDS) and strides >= 64 are register-local.  Loads of x and the
+// f64 (cos,sin) stores are fully coalesced (256 B / 1 KiB per wave instruction).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/xgpr_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// host-side helpers
+// ------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char *msg) { g_err = msg; return code; }
+
+int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return XGPR_ERR_HIP;
+}
+
+#define HIP_TRY(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, what); } while (0)
+
+// padded SORF width: rbf_ops.cpp:56-59 / rbf_convolution.cpp:60-64
+long padded_width(long w) {
+    double e = w > 2 ? (double)w : 2.0;
+    return (long)pow(2.0, ceil(log2(e)));
+}
+
+// the SORF / SRHT normaliser, computed in T exactly as shared_rfgen_ops.cpp:54-55 does
+template <typename T> T norm_constant(long dim) {
+    T nc = (T)(log2((double)dim) / 2);
+    nc = (T)(1 / pow(2.0, (double)nc));
+    return nc;
+}
+
+int ilog2(long v) { int l = 0; while ((1L << l) < v) l++; return l; }
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------
+// device math
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float as_f(int x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ int as_i(float x) { return __builtin_bit_cast(int, x); }
+
+// Rare path of sincos_f32 (|v| >= 2^18, inf, nan): double-precision Cody-Waite, or the
+// ocml functions for arguments whose quadrant index would not fit an int.
+__device__ __attribute__((noinline)) float2 sincos_slow(float v) {
+    if (fabsf(v) < 1.0e9f) {
+        double vd = (double)v;
+        double kd = __builtin_rint(vd * 0.63661977236758134308);
+        double r = __builtin_fma(kd, -1.57079632679489655800e+00, vd);
+        r = __builtin_fma(kd, -6.12323399573676603587e-17, r);
+        long q = (long)kd;
+        double sd, cd;
+        sd = sin(r); cd = cos(r);
+        double ss = (q & 1) ? cd : sd;
+        double cc = (q & 1) ? sd : cd;
+        if (q & 2) ss = -ss;
+        if ((q + 1) & 2) cc = -cc;
+        return make_float2((float)ss, (float)cc);
+    }
+    return make_float2(sinf(v), cosf(v));
+}
+
+// sin and cos of a float argument, <= 1.6 ulp each for |v| < 2^18 (max abs error 9.3e-8,
+// measured against double-precision libm over 4e7 arguments): Cody-Waite reduction by pi/2
+// in three fmas + the Cephes single-precision kernels on [-pi/4, pi/4].  The reference
+// evaluates glibc cosf/sinf (<1 ulp), so features agree to ~2 ulp(f32) * scale.
+__device__ __forceinline__ void sincos_f32(float v, float &s, float &c) {
+    float kf = __builtin_rintf(v * 0.6366197466850281f);
+    float r = __builtin_fmaf(kf, -1.5707963705062866f, v);
+    r = __builtin_fmaf(kf, 4.371138828673793e-08f, r);
+    r = __builtin_fmaf(kf, 1.7151245100058819e-15f, r);
+    int q = (int)kf;
+    float r2 = r * r;
+    float ps = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2,
+                              -1.6666654611e-1f), r2 * r, r);
+    float pc = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2,
+                              4.166664568298827e-2f), r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+    float ss = (q & 1) ? pc : ps;
+    float cc = (q & 1) ? ps : pc;
+    s = as_f(as_i(ss) ^ ((q & 2) << 30));
+    c = as_f(as_i(cc) ^ (((q + 1) & 2) << 30));
+    if (__builtin_expect(!(fabsf(v) < 262144.0f), 0)) {
+        float2 sc = sincos_slow(v);
+        s = sc.x; c = sc.y;
+    }
+}
+
+template <typename T> struct Math;
+template <> struct Math<float> {
+    static __device__ __forceinline__ void sincos(float v, float &s, float &c) { sincos_f32(v, s, c); }
+};
+template <> struct Math<double> {
+    static __device__ __forceinline__ void sincos(double v, double &s, double &c) { s = sin(v); c = cos(v); }
+};
+
+// ------------------------------------------------------------------------------------
+// generic (any width) path: one workgroup per transform, butterflies in LDS.
+// Used for P > 1024, for double precision, for the gradient ops and as the bare FHT / SRHT.
+// ------------------------------------------------------------------------------------
+
+// In-place FHT of every aligned P-block of buf[0:len) (len a multiple of P), stages in the
+// reference's order h = 1, 2, 4, ...; two stages per barrier (radix-4 pass = stage h then
+// stage 2h with identical operand pairing, so every rounding matches the radix-2 chain).
+template <typename T>
+__device__ __forceinline__ void lds_fht(T *buf, int len, int P, int tid, int nt) {
+    int h = 1;
+    for (; (h << 1) < P; h <<= 2) {
+        for (int idx = tid; idx < (len >> 2); idx += nt) {
+            int lo = idx & (h - 1);
+            int j = ((idx - lo) << 2) | lo;
+            T a = buf[j], b = buf[j + h], c = buf[j + 2 * h], d = buf[j + 3 * h];
+            T ab = a + b, amb = a - b, cd = c + d, cmd = c - d;
+            buf[j] = ab + cd;
+            buf[j + h] = amb + cmd;
+            buf[j + 2 * h] = ab - cd;
+            buf[j + 3 * h] = amb - cmd;
+        }
+        __syncthreads();
+    }
+    if (h < P) {
+        for (int idx = tid; idx < (len >> 1); idx += nt) {
+            int lo = idx & (h - 1);
+            int j = ((idx - lo) << 1) | lo;
+            T a = buf[j], b = buf[j + h];
+            buf[j] = a + b;
+            buf[j + h] = a - b;
+        }
+        __syncthreads();
+    }
+}
+
+// bare FHT / SRHT over a flat array of `total` elements made of vectors of length P.
+// Each workgroup owns CH consecutive elements (CH a multiple of P, or CH < P when P exceeds
+// the LDS capacity, in which case the stages h >= CH are finished by global_stage_kernel).
+template <typename T, bool SRHT>
+__global__ void generic_fht_kernel(T *x, const int8_t *__restrict__ radem, long total, int P, int CH, T nc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *buf = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long base = (long)blockIdx.x * CH;
+    for (int e = tid; e < CH; e += nt) {
+        long idx = base + e;
+        T val = idx < total ? x[idx] : (T)0;
+        if (SRHT && idx < total) val *= radem[idx & (long)(P - 1)] * nc;
+        buf[e] = val;
+    }
+    __syncthreads();
+    lds_fht<T>(buf, CH, P < CH ? P : CH, tid, nt);
+    for (int e = tid; e < CH; e += nt) {
+        long idx = base + e;
+        if (idx < total) x[idx] = buf[e];
+    }
+}
+
+// one butterfly stage of stride h straight in global memory (only for P > LDS capacity)
+template <typename T>
+__global__ void global_stage_kernel(T *x, long npairs, long h) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npairs) return;
+    long lo = idx & (h - 1);
+    long j = ((idx - lo) << 1) | lo;
+    T a = x[j], b = x[j + h];
+    x[j] = a + b;
+    x[j + h] = a - b;
+}
+
+enum { MODE_RBF = 0, MODE_RBF_GRAD = 1, MODE_CONV = 2, MODE_CONV_GRAD = 3, MODE_MAXPOOL = 4 };
+
+template <typename T> struct SorfArgs {
+    const T *x; double *out; double *grad; float *outf;
+    const int8_t *radem; const T *chi; const int32_t *seqlen;
+    long n; long row_stride; long F; long R;
+    int d;            // elements copied per transform (input width, or conv_width * C)
+    int kmer_stride;  // C for the conv ops
+    int conv_width; int P; int reps; int scaling_type;
+    T nc; double scale; double sigma;
+};
+
+// one workgroup per (datapoint i = blockIdx.x, repeat k = blockIdx.y); for the conv ops the
+// k-mer loop runs inside the workgroup in the reference's order (j ascending), each thread
+// owning its output elements, so the f64 accumulation order equals the reference's.
+template <typename T, int MODE>
+__global__ void generic_sorf_kernel(SorfArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *buf = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long i = blockIdx.x;
+    const int k = blockIdx.y;
+    const int P = a.P;
+    constexpr bool CONVLIKE = (MODE == MODE_CONV || MODE == MODE_CONV_GRAD || MODE == MODE_MAXPOOL);
+    int nk = 1;
+    double rs = a.scale;
+    if (CONVLIKE) {
+        nk = a.seqlen[i] - a.conv_width + 1;
+        if (MODE != MODE_MAXPOOL) {
+            if (a.scaling_type == 1) rs = a.scale / sqrt((double)nk);
+            else if (a.scaling_type == 2) rs = a.scale / (double)nk;
+        }
+    }
+    const int out0 = k * P;
+    long endp = a.F < (long)(k + 1) * P ? a.F : (long)(k + 1) * P;
+    const int cnt = (int)(endp - out0);
+    const int8_t *re = a.radem + out0;
+
+    for (int j = 0; j < nk; j++) {
+        const T *xe = a.x + i * a.row_stride + (long)j * a.kmer_stride;
+        for (int e = tid; e < P; e += nt) buf[e] = e < a.d ? xe[e] : (T)0;
+        for (int s = 0; s < 3; s++) {
+            // same thread touches the same elements as in the load above / the pass below
+            for (int e = tid; e < P; e += nt) buf[e] *= re[(long)s * a.R + e] * a.nc;
+            __syncthreads();
+            lds_fht<T>(buf, P, P, tid, nt);
+        }
+        for (int e = tid; e < cnt; e += nt) {
+            const T chv = a.chi[out0 + e];
+            if (MODE == MODE_RBF || MODE == MODE_CONV) {
+                T prod = buf[e] * chv;
+                T sn, cs;
+                Math<T>::sincos(prod, sn, cs);
+                double *o = a.out + i * 2 * a.F + 2 * (long)(out0 + e);
+                if (MODE == MODE_RBF) {
+                    double2 val = make_double2(cs * rs, sn * rs);
+                    *reinterpret_cast<double2 *>(o) = val;
+                } else {
+                    o[0] += cs * rs;
+                    o[1] += sn * rs;
+                }
+            } else if (MODE == MODE_RBF_GRAD || MODE == MODE_CONV_GRAD) {
+                // shared_rfgen_ops.cpp:140-155, including the roundings back to T
+                T grad_val = buf[e] * chv;
+                T prod_val = (T)(grad_val * a.sigma);
+                T sn, cs;
+                Math<T>::sincos(prod_val, sn, cs);
+                T cos_val = (T)(cs * rs);
+                T sin_val = (T)(sn * rs);
+                double *o = a.out + i * 2 * a.F + 2 * (long)(out0 + e);
+                double *g = a.grad + i * 2 * a.F + 2 * (long)(out0 + e);
+                T gs = sin_val * grad_val, gc = cos_val * grad_val;
+                if (MODE == MODE_RBF_GRAD) {
+                    o[0] = cos_val; o[1] = sin_val;
+                    g[0] = -(double)gs; g[1] = gc;
+                } else {
+                    o[0] += cos_val; o[1] += sin_val;
+                    g[0] -= gs; g[1] += gc;
+                }
+            } else {  // MODE_MAXPOOL: conv1d_operations.cpp:160-166
+                float prod = (float)(buf[e] * chv);
+                float *o = a.outf + i * a.F + out0 + e;
+                float old = *o;
+                *o = old > prod ? old : prod;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Rademacher sign masks: masks[s * MW + g] bit l = (radem[s, 0, 64 g + l] < 0); one 64-bit
+// lane mask per (diagonal s, group of 64 frequencies), zero beyond R.  MW is R rounded up to
+// a multiple of 1024, over 64 -- so a wave tile's 16 masks per diagonal are always in range.
+// The masks are wave-uniform, so the kernels read them with scalar loads and apply them with
+// one v_cndmask per element.
+// ------------------------------------------------------------------------------------
+__global__ void pack_radem_kernel(const int8_t *__restrict__ radem, uint64_t *masks, long R, int MW) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (item >= 3L * MW) return;
+    const int s = (int)(item / MW);
+    const long g = item % MW;
+    const long f = g * 64 + lane;
+    int8_t val = f < R ? radem[(long)s * R + f] : (int8_t)1;
+    uint64_t m = __ballot(val < 0);
+    if (lane == 0) masks[item] = m;
+}
+
+// ------------------------------------------------------------------------------------
+// wave-level FHT (P <= 1024, float)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void bfly(float &a, float &b) {
+    float s = a + b, d = a - b;
+    a = s; b = d;
+}
+
+// cross-lane butterfly of stride H (< 64) on all 16 registers: lanes with bit H clear get
+// x + partner, lanes with bit H set get partner - x, partner = lane ^ H.
+template <int H> __device__ __forceinline__ void xstage(float (&v)[16], int lane) {
+    if constexpr (H == 1 || H == 2 || H == 8) {
+        // partner through a DPP operand (quad_perm / row_ror:8), own term with the sign folded in
+        const int sm = (lane & H) ? (int)0x80000000 : 0;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int xi = as_i(v[r]);
+            int p;
+            if constexpr (H == 1) p = __builtin_amdgcn_mov_dpp(xi, 0xB1, 0xf, 0xf, true);       // quad_perm:[1,0,3,2]
+            else if constexpr (H == 2) p = __builtin_amdgcn_mov_dpp(xi, 0x4E, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
+            else p = __builtin_amdgcn_mov_dpp(xi, 0x128, 0xf, 0xf, true);                        // row_ror:8
+            v[r] = as_f(xi ^ sm) + as_f(p);
+        }
+    } else if constexpr (H == 4) {
+        // lane^4 is row_ror:12 (lane+4) for DPP banks 0,2 and row_ror:4 (lane-4) for banks 1,3:
+        // two bank-masked DPP ops write the butterfly directly.  s_nop 1 covers the
+        // VALU-write -> DPP-read hazard on both sides (the compiler cannot see into the asm).
+        #pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            float o0, o1, o2, o3, o4, o5, o6, o7;
+            asm volatile(
+                "s_nop 1\n\t"
+                "v_add_f32_dpp %0, %8, %8 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %1, %9, %9 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %2, %10, %10 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %3, %11, %11 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %4, %12, %12 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %5, %13, %13 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %6, %14, %14 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %7, %15, %15 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                "v_sub_f32_dpp %0, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_sub_f32_dpp %1, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_sub_f32_dpp %2, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_sub_f32_dpp %3, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_sub_f32_dpp %4, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_sub_f32_dpp %5, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_sub_f32_dpp %6, %14, %14 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "v_sub_f32_dpp %7, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                "s_nop 1"
+                : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5), "=&v"(o6), "=&v"(o7)
+                : "v"(v[r0]), "v"(v[r0 + 1]), "v"(v[r0 + 2]), "v"(v[r0 + 3]), "v"(v[r0 + 4]), "v"(v[r0 + 5]),
+                  "v"(v[r0 + 6]), "v"(v[r0 + 7]));
+            v[r0] = o0; v[r0 + 1] = o1; v[r0 + 2] = o2; v[r0 + 3] = o3;
+            v[r0 + 4] = o4; v[r0 + 5] = o5; v[r0 + 6] = o6; v[r0 + 7] = o7;
+        }
+    } else {
+        // H = 16 / 32: v_permlane16_swap / v_permlane32_swap on a register pair (A, B) puts the
+        // two butterfly operands of both registers into the same lanes: swap, add/sub, swap back.
+        #pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            int a = as_i(v[r]), b = as_i(v[r + 1]);
+            if constexpr (H == 16) {
+                auto t = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+                float s = as_f(t[0]) + as_f(t[1]), d = as_f(t[0]) - as_f(t[1]);
+                auto u = __builtin_amdgcn_permlane16_swap(as_i(s), as_i(d), false, false);
+                v[r] = as_f(u[0]); v[r + 1] = as_f(u[1]);
+            } else {
+                auto t = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                float s = as_f(t[0]) + as_f(t[1]), d = as_f(t[0]) - as_f(t[1]);
+                auto u = __builtin_amdgcn_permlane32_swap(as_i(s), as_i(d), false, false);
+                v[r] = as_f(u[0]); v[r + 1] = as_f(u[1]);
+            }
+        }
+    }
+}
+
+// FHT of every length-P transform in the wave tile, stages h = 1, 2, ..., P/2 in order.
+template <int LOG2P> __device__ __forceinline__ void wave_fht(float (&v)[16], int lane) {
+    constexpr int P = 1 << LOG2P;
+    if constexpr (P > 1) xstage<1>(v, lane);
+    if constexpr (P > 2) xstage<2>(v, lane);
+    if constexpr (P > 4) xstage<4>(v, lane);
+    if constexpr (P > 8) xstage<8>(v, lane);
+    if constexpr (P > 16) xstage<16>(v, lane);
+    if constexpr (P > 32) xstage<32>(v, lane);
+    #pragma unroll
+    for (int q = 1; q < P / 64; q <<= 1) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (!(r & q)) bfly(v[r], v[r + q]);
+    }
+}
+
+// three rounds of { x *= radem * norm ; FHT }.  mk points at this tile's first mask of
+// diagonal 0; diagonal s is MW masks further on.  For even log2(P) the normaliser is an
+// exact power of two and is folded into chi by the caller (exact), so only the sign flip
+// remains; for odd log2(P) the rounded constant is applied per round as the reference does.
+template <int LOG2P>
+__device__ __forceinline__ void wave_sorf(float (&v)[16], const uint64_t *__restrict__ mk, int MW, float nc, int lane) {
+    #pragma unroll
+    for (int s = 0; s < 3; s++) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            uint64_t m = mk[s * MW + r];
+            float t = (LOG2P & 1) ? v[r] * nc : v[r];
+            v[r] = __builtin_amdgcn_inverse_ballot_w64(m) ? -t : t;
+        }
+        wave_fht<LOG2P>(v, lane);
+    }
+}
+
+// load one datapoint (or k-mer window) into the wave tile: element (64 r + l) mod P, zero
+// padded from d up to P, replicated over the tile's 1024 / P transforms.
+template <int LOG2P>
+__device__ __forceinline__ void wave_load(float (&v)[16], const float *__restrict__ xe, int d, int lane) {
+    constexpr int P = 1 << LOG2P;
+    if constexpr (P >= 64) {
+        constexpr int RP = P / 64;
+        #pragma unroll
+        for (int r = 0; r < RP; r++) {
+            int e = r * 64 + lane;
+            v[r] = e < d ? xe[e] : 0.0f;
+        }
+        #pragma unroll
+        for (int r = RP; r < 16; r++) v[r] = v[r & (RP - 1)];
+    } else {
+        int e = lane & (P - 1);
+        float t = e < d ? xe[e] : 0.0f;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = t;
+    }
+}
+
+struct WaveArgs {
+    const float *x; double *out; float *outf;
+    const uint64_t *masks; const float *chi; const int32_t *seqlen;
+    const double *vec; double *wpart;
+    long n; long row_stride; long F;
+    int d; int kmer_stride; int conv_width; int scaling_type;
+    int MW; int nb;           // masks per diagonal; wave tiles (1024 frequencies) per datapoint
+    int G;                    // matvec: datapoints in flight per workgroup
+    int fit_intercept;
+    float nc; float chi_scale; // per-round normaliser (odd log2 P) / folded normaliser^3 (even)
+    double scale;
+};
+
+// ---- cudaRBFFeatureGen: one wave per (datapoint, tile); 4 waves per workgroup.
+template <int LOG2P>
+__global__ __launch_bounds__(256) void wave_rbf_kernel(WaveArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long item = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (long)blockIdx.x * 4;
+    if (item >= a.n * a.nb) return;
+    const long i = item / a.nb;
+    const int b = (int)(item % a.nb);
+    float v[16];
+    wave_load<LOG2P>(v, a.x + i * a.row_stride, a.d, lane);
+    wave_sorf<LOG2P>(v, a.masks + (long)b * 16, a.MW, a.nc, lane);
+    const long f0 = (long)b * 1024 + lane;
+    double *orow = a.out + i * 2 * a.F;
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long f = f0 + r * 64;
+        if (f < a.F) {
+            float prod = v[r] * (a.chi[f] * a.chi_scale);
+            float sn, cs;
+            sincos_f32(prod, sn, cs);
+            double2 val = make_double2(cs * a.scale, sn * a.scale);
+            *reinterpret_cast<double2 *>(orow + 2 * f) = val;
+        }
+    }
+}
+
+// ---- cudaConv1dFGen / cudaConv1dMaxpool: one wave per (sequence, tile), k-mers looped inside
+// the wave in the reference's order, sums kept in registers, one read-modify-write at the end.
+template <int LOG2P, bool MAXPOOL>
+__global__ __launch_bounds__(256) void wave_conv_kernel(WaveArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long item = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (long)blockIdx.x * 4;
+    if (item >= a.n * a.nb) return;
+    const long i = item / a.nb;
+    const int b = (int)(item % a.nb);
+    const int nk = a.seqlen[i] - a.conv_width + 1;
+    const long f0 = (long)b * 1024 + lane;
+    float ch[16];
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long f = f0 + r * 64;
+        ch[r] = f < a.F ? a.chi[f] * a.chi_scale : 0.0f;
+    }
+    const uint64_t *mk = a.masks + (long)b * 16;
+    const float *xrow = a.x + i * a.row_stride;
+    if constexpr (MAXPOOL) {
+        float acc[16];
+        float *orow = a.outf + i * a.F;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long f = f0 + r * 64;
+            acc[r] = f < a.F ? orow[f] : 0.0f;
+        }
+        for (int j = 0; j < nk; j++) {
+            float v[16];
+            wave_load<LOG2P>(v, xrow + (long)j * a.kmer_stride, a.d, lane);
+            wave_sorf<LOG2P>(v, mk, a.MW, a.nc, lane);
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float prod = v[r] * ch[r];
+                acc[r] = acc[r] > prod ? acc[r] : prod;
+            }
+        }
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long f = f0 + r * 64;
+            if (f < a.F) orow[f] = acc[r];
+        }
+    } else {
+        double ac[16], as[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { ac[r] = 0.0; as[r] = 0.0; }
+        for (int j = 0; j < nk; j++) {
+            float v[16];
+            wave_load<LOG2P>(v, xrow + (long)j * a.kmer_stride, a.d, lane);
+            wave_sorf<LOG2P>(v, mk, a.MW, a.nc, lane);
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float sn, cs;
+                sincos_f32(v[r] * ch[r], sn, cs);
+                ac[r] += (double)cs;
+                as[r] += (double)sn;
+            }
+        }
+        double rs = a.scale;
+        if (a.scaling_type == 1) rs = a.scale / sqrt((double)nk);
+        else if (a.scaling_type == 2) rs = a.scale / (double)nk;
+        double *orow = a.out + i * 2 * a.F;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long f = f0 + r * 64;
+            if (f < a.F) {
+                double2 *o = reinterpret_cast<double2 *>(orow + 2 * f);
+                double2 old = *o;
+                old.x += ac[r] * rs;
+                old.y += as[r] * rs;
+                *o = old;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double u) {
+    #pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) u += __shfl_xor(u, h);
+    return u;
+}
+
+// ---- fused CG matvec / z^T y.  A workgroup holds G datapoints in flight; datapoint slot g is
+// served by nb waves, wave (g, b) owning tile b = frequencies [1024 b, 1024 b + 1024): its
+// slice of v (MATVEC) and its f64 accumulators stay in registers for the whole launch while
+// the workgroup strides over its datapoints.  Per datapoint: SORF -> cos/sin (registers) ->
+// partial dot with v -> nb partials meet in LDS (one barrier, double-buffered) -> rank-1
+// update of the accumulators.  Z is never written.  At the end every slot writes its
+// accumulators as one slab wpart[slot, :]; reduce_slabs_kernel adds the slabs in slot order.
+template <int LOG2P, bool MATVEC>
+__global__ __launch_bounds__(512, 2) void wave_ztz_kernel(WaveArgs a) {
+    __shared__ double part[2][16];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = w % a.nb;
+    const int g = w / a.nb;
+    const long slot = (long)blockIdx.x * a.G + g;
+    const long nslots = (long)gridDim.x * a.G;
+    const long iters = (a.n + nslots - 1) / nslots;
+    const long f0 = (long)b * 1024 + lane;
+    const uint64_t *mk = a.masks + (long)b * 16;
+
+    float ch[16];
+    double pc[16], ps[16], ac[16], as[16];
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long f = f0 + r * 64;
+        const bool ok = f < a.F;
+        ch[r] = ok ? a.chi[f] * a.chi_scale : 0.0f;
+        ac[r] = 0.0; as[r] = 0.0;
+        if (MATVEC) {
+            double2 p = ok ? *reinterpret_cast<const double2 *>(a.vec + 2 * f) : make_double2(0.0, 0.0);
+            pc[r] = p.x; ps[r] = p.y;
+        }
+    }
+    // Z[:, 0] = 1 (kernel_baseclass.py:296-297): feature (f = 0, cos) is 1 / scale before scaling
+    const bool icpt = a.fit_intercept && b == 0 && lane == 0;
+    const double inv_scale = 1.0 / a.scale;
+    const double s2 = a.scale * a.scale;
+
+    for (long it = 0; it < iters; it++) {
+        const long row = it * nslots + slot;
+        const bool active = row < a.n;
+        float cs[16], sn[16];
+        double u = 0.0;
+        if (active) {
+            float v[16];
+            wave_load<LOG2P>(v, a.x + row * a.row_stride, a.d, lane);
+            wave_sorf<LOG2P>(v, mk, a.MW, a.nc, lane);
+            #pragma unroll
+            for (int r = 0; r < 16; r++) sincos_f32(v[r] * ch[r], sn[r], cs[r]);
+        } else {
+            #pragma unroll
+            for (int r = 0; r < 16; r++) { cs[r] = 0.0f; sn[r] = 0.0f; }
+        }
+        double c0 = icpt ? inv_scale : (double)cs[0];
+        if (MATVEC) {
+            u = __builtin_fma(c0, pc[0], u);
+            u = __builtin_fma((double)sn[0], ps[0], u);
+            #pragma unroll
+            for (int r = 1; r < 16; r++) {
+                u = __builtin_fma((double)cs[r], pc[r], u);
+                u = __builtin_fma((double)sn[r], ps[r], u);
+            }
+            u = wave_sum(u);
+            if (lane == 0) part[it & 1][w] = u;
+            __syncthreads();
+            double t = 0.0;
+            for (int bb = 0; bb < a.nb; bb++) t += part[it & 1][g * a.nb + bb];
+            u = t * s2;
+        } else {
+            u = active ? a.vec[row] * a.scale : 0.0;   // y[row] * scale
+        }
+        if (active) {
+            ac[0] = __builtin_fma(c0, u, ac[0]);
+            as[0] = __builtin_fma((double)sn[0], u, as[0]);
+            #pragma unroll
+            for (int r = 1; r < 16; r++) {
+                ac[r] = __builtin_fma((double)cs[r], u, ac[r]);
+                as[r] = __builtin_fma((double)sn[r], u, as[r]);
+            }
+        }
+    }
+    double *slab = a.wpart + slot * 2 * a.F;
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long f = f0 + r * 64;
+        if (f < a.F) *reinterpret_cast<double2 *>(slab + 2 * f) = make_double2(ac[r], as[r]);
+    }
+}
+
+// w_out[m] = sum over slabs (fixed order) of wpart[slab, m]; 64 columns x 4 slab phases per
+// workgroup, each thread 8 independent partial sums to keep loads in flight.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const double *__restrict__ wpart, double *w_out, long M,
+                                                           long nslabs) {
+    __shared__ double red[4][64];
+    const int col = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long m = (long)blockIdx.x * 64 + col;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m < M) {
+        long k = ph;
+        for (; k + 28 < nslabs; k += 32) {
+            #pragma unroll
+            for (int q = 0; q < 8; q++) s[q] += wpart[(k + 4 * q) * M + m];
+        }
+        double tail = 0.0;
+        for (; k < nslabs; k += 4) tail += wpart[k * M + m];
+        s[0] += tail;
+    }
+    red[ph][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (ph == 0 && m < M) w_out[m] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+// ---- self test of the cross-lane stages: v[r] = lane + 64 r, one stage of stride H,
+// registers 0 and 1 written out.  Expected: bit H of lane clear -> 2 lane + H + 128 r, set -> -H.
+__global__ void selftest_kernel(int32_t *out) {
+    const int lane = threadIdx.x & 63;
+    float v[16];
+    #pragma unroll
+    for (int q = 0; q < 6; q++) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = (float)(lane + 64 * r);
+        if (q == 0) xstage<1>(v, lane);
+        else if (q == 1) xstage<2>(v, lane);
+        else if (q == 2) xstage<4>(v, lane);
+        else if (q == 3) xstage<8>(v, lane);
+        else if (q == 4) xstage<16>(v, lane);
+        else xstage<32>(v, lane);
+        #pragma unroll
+        for (int r = 0; r < 16; r++) out[(q * 16 + r) * 64 + lane] = (int32_t)v[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+constexpr long LDS_CAP_BYTES = 128 * 1024;   // per-workgroup LDS the generic path will ask for
+
+template <typename T> long lds_cap_elems() { return LDS_CAP_BYTES / (long)sizeof(T); }
+
+template <typename K> int allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return 0;
+}
+
+int threads_for(long P) { return P >= 4096 ? 1024 : (P >= 512 ? 256 : 64); }
+
+template <typename T, bool SRHT>
+int launch_fht(T *x, const int8_t *radem, long nvec, long P, hipStream_t st) {
+    const long total = nvec * P;
+    const long cap = lds_cap_elems<T>();
+    long CH;
+    if (P <= cap) {
+        CH = P >= 1024 ? P : 1024;   // several short vectors per workgroup
+    } else {
+        CH = cap;
+    }
+    const long nblocks = (total + CH - 1) / CH;
+    const size_t lds = (size_t)CH * sizeof(T);
+    auto kern = generic_fht_kernel<T, SRHT>;
+    int rc = allow_big_lds(kern, lds);
+    if (rc) return rc;
+    const T nc = SRHT ? norm_constant<T>(P) : (T)1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(threads_for(CH)), lds, st, x, radem, total, (int)P, (int)CH, nc);
+    HIP_TRY(hipGetLastError(), "generic_fht_kernel launch");
+    for (long h = CH; h < P; h <<= 1) {
+        const long npairs = total / 2;
+        hipLaunchKernelGGL(global_stage_kernel<T>, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, x, npairs, h);
+        HIP_TRY(hipGetLastError(), "global_stage_kernel launch");
+    }
+    return 0;
+}
+
+template <typename T, int MODE>
+int launch_generic_sorf(const SorfArgs<T> &a, hipStream_t st) {
+    if ((long)a.P > lds_cap_elems<T>())
+        return fail(XGPR_ERR_UNSUPPORTED, "padded width exceeds the LDS-resident limit (32768 float / 16384 double)");
+    const size_t lds = (size_t)a.P * sizeof(T);
+    auto kern = generic_sorf_kernel<T, MODE>;
+    int rc = allow_big_lds(kern, lds);
+    if (rc) return rc;
+    if (a.n > 2147483647L || a.reps > 65535)
+        return fail(XGPR_ERR_UNSUPPORTED, "grid too large for the generic path");
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.n, (unsigned)a.reps), dim3(threads_for(a.P)), lds, st, a);
+    HIP_TRY(hipGetLastError(), "generic_sorf_kernel launch");
+    return 0;
+}
+
+int pack_masks(const int8_t *radem, uint64_t *masks, long R, int MW, hipStream_t st) {
+    const long items = 3L * MW;
+    hipLaunchKernelGGL(pack_radem_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, radem, masks, R, MW);
+    HIP_TRY(hipGetLastError(), "pack_radem_kernel launch");
+    return 0;
+}
+
+int masks_per_diag(long R) { return (int)(align_up((size_t)R, 1024) / 64); }
+size_t masks_bytes(long R) { return align_up((size_t)3 * masks_per_diag(R) * sizeof(uint64_t), 256); }
+
+#define DISPATCH_LOG2P(lg, CALL)                                                 \
+    switch (lg) {                                                                \
+        case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break;  \
+        case 4: CALL(4); break; case 5: CALL(5); break; case 6: CALL(6); break;  \
+        case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break;  \
+        case 10: CALL(10); break;                                                \
+        default: return fail(XGPR_ERR_UNSUPPORTED, "padded width > 1024 on the wave path"); \
+    }
+
+void fill_norms(WaveArgs &a, int lg) {
+    const float nc = norm_constant<float>(1L << lg);
+    if (lg & 1) { a.nc = nc; a.chi_scale = 1.0f; }
+    else { a.nc = 1.0f; a.chi_scale = nc * nc * nc; }   // exact power of two
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------
+// validation shared by the entry points (mirrors the reference's throw sites)
+// ------------------------------------------------------------------------------------
+int check_seqlens(const int32_t *seqlen_host, long nseq, long n, long L, int conv_width) {
+    if (nseq != n) return fail(XGPR_ERR_SEQLEN_SIZE, "wrong array sizes");
+    if (L < conv_width || conv_width <= 0) return fail(XGPR_ERR_CONV_WIDTH, "invalid conv_width");
+    if (!seqlen_host) return fail(XGPR_ERR_SEQLEN_RANGE, "seqlen_host is required (sequence lengths are validated on the host)");
+    int32_t mn = 2147483647, mx = 0;
+    for (long i = 0; i < nseq; i++) {
+        if (seqlen_host[i] > mx) mx = seqlen_host[i];
+        if (seqlen_host[i] < mn) mn = seqlen_host[i];
+    }
+    if (mx > L || mn < conv_width)
+        return fail(XGPR_ERR_SEQLEN_RANGE, "All sequence lengths must be >= conv width and < array size.");
+    return 0;
+}
+
+template <typename T> double rbf_scale(long num_freqs, int fit_intercept) {
+    // rbf_ops.cpp:64-69: the constant is rounded to T there
+    T s = fit_intercept ? (T)sqrt(1.0 / ((double)num_freqs - 0.5)) : (T)sqrt(1.0 / (double)num_freqs);
+    return (double)s;
+}
+
+// ------------------------------------------------------------------------------------
+// typed implementations behind the C entry points
+// ------------------------------------------------------------------------------------
+template <typename T>
+int fht_impl(T *x, long n, long dim1, long dim2, void *stream) {
+    if (n == 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (dim2 < 2) return fail(XGPR_ERR_NOT_POW2, "last dim not power of 2 > 1");
+    if ((dim2 & (dim2 - 1)) != 0) return fail(XGPR_ERR_NOT_POW2, "last dim not power of 2");
+    if (dim1 < 1) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    return launch_fht<T, false>(x, nullptr, n * dim1, dim2, (hipStream_t)stream);
+}
+
+template <typename T>
+int srht_impl(T *x, const int8_t *radem, long n, long dim, long radem_len, void *stream) {
+    if (n == 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (dim != radem_len) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (dim < 2) return fail(XGPR_ERR_NOT_POW2, "last dim not power of 2 > 1");
+    if ((dim & (dim - 1)) != 0) return fail(XGPR_ERR_NOT_POW2, "last dim not power of 2");
+    return launch_fht<T, true>(x, radem, n, dim, (hipStream_t)stream);
+}
+
+template <typename T>
+int rbf_impl(const T *x, double *out, double *grad, const int8_t *radem, const T *chi, long n, long d,
+             long out_rows, long num_rffs, long grad_rows, long grad_cols, long num_freqs, long R,
+             double sigma, int fit_intercept, bool want_grad, void *workspace, size_t wbytes, void *stream) {
+    const long P = padded_width(d);
+    if (n == 0 || out_rows != n) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (num_rffs < 2 || (num_rffs & 1) != 0) return fail(XGPR_ERR_ODD_OUTPUT, "last dim of output must be even number");
+    if (2 * num_freqs != num_rffs || num_freqs > R) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    if (want_grad && (grad_rows != out_rows || grad_cols != num_rffs)) return fail(XGPR_ERR_ARRAY_SIZES, "Wrong array sizes.");
+    if (R % P != 0) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    if (!aligned16(out)) return fail(XGPR_ERR_WORKSPACE, "output pointer must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int reps = (int)((num_freqs + P - 1) / P);
+
+    if constexpr (sizeof(T) == 4) {
+        if (!want_grad && P <= 1024) {
+            if (!workspace || wbytes < masks_bytes(R)) return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_rbf_workspace_bytes)");
+            WaveArgs a = {};
+            a.x = x; a.out = out; a.masks = (const uint64_t *)workspace; a.chi = chi;
+            a.n = n; a.row_stride = d; a.F = num_freqs; a.d = (int)d;
+            a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
+            a.scale = rbf_scale<float>(num_freqs, fit_intercept);
+            const int lg = ilog2(P);
+            fill_norms(a, lg);
+            int rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
+            if (rc) return rc;
+            const long items = n * a.nb;
+            const long nblocks = (items + 3) / 4;
+            if (nblocks > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
+#define CALL_RBF(LG) hipLaunchKernelGGL(wave_rbf_kernel<LG>, dim3((unsigned)nblocks), dim3(256), 0, st, a)
+            DISPATCH_LOG2P(lg, CALL_RBF)
+#undef CALL_RBF
+            HIP_TRY(hipGetLastError(), "wave_rbf_kernel launch");
+            return 0;
+        }
+    }
+    SorfArgs<T> a = {};
+    a.x = x; a.out = out; a.grad = grad; a.radem = radem; a.chi = chi;
+    a.n = n; a.row_stride = d; a.F = num_freqs; a.R = R; a.d = (int)d;
+    a.P = (int)P; a.reps = reps; a.nc = norm_constant<T>(P); a.sigma = sigma;
+    if (want_grad) {
+        // rbf_ops.cpp:180-185: a double constant in the gradient op
+        a.scale = fit_intercept ? sqrt(1.0 / ((double)num_freqs - 0.5)) : sqrt(1.0 / (double)num_freqs);
+        return launch_generic_sorf<T, MODE_RBF_GRAD>(a, st);
+    }
+    a.scale = rbf_scale<T>(num_freqs, fit_intercept);
+    return launch_generic_sorf<T, MODE_RBF>(a, st);
+}
+
+template <typename T>
+int conv_impl(const T *x, double *out, double *grad, float *outf, const int8_t *radem, const T *chi,
+              const int32_t *seqlen_host, const int32_t *seqlen_dev, long n, long L, long C, long out_rows,
+              long num_rffs, long grad_rows, long grad_cols, long num_freqs, long R, long nseq, double sigma,
+              int conv_width, int scaling_type, int mode, void *workspace, size_t wbytes, void *stream) {
+    if (n == 0 || out_rows != n) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (num_rffs < 2 || (num_rffs & 1) != 0) return fail(XGPR_ERR_ODD_OUTPUT, "last dim of output must be even number");
+    if (mode == MODE_MAXPOOL) {
+        if (num_freqs != num_rffs || num_freqs > R) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    } else {
+        if (2 * num_freqs != num_rffs || num_freqs > R) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    }
+    if (mode == MODE_CONV_GRAD && (grad_rows != out_rows || grad_cols != num_rffs))
+        return fail(XGPR_ERR_ARRAY_SIZES, "Wrong array sizes.");
+    if (nseq != n) return fail(XGPR_ERR_SEQLEN_SIZE, "wrong array sizes");
+    if (L < conv_width || conv_width <= 0) return fail(XGPR_ERR_CONV_WIDTH, "invalid conv_width");
+    const long win = (long)conv_width * C;
+    const long P = padded_width(win);
+    const int reps = (int)((num_freqs + P - 1) / P);
+    if (R % P != 0) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    if (mode == MODE_MAXPOOL && R != (long)reps * P) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    int rc = check_seqlens(seqlen_host, nseq, n, L, conv_width);
+    if (rc) return rc;
+    if (!seqlen_dev) return fail(XGPR_ERR_WORKSPACE, "seqlen_dev (device copy of the sequence lengths) is required");
+    hipStream_t st = (hipStream_t)stream;
+
+    if constexpr (sizeof(T) == 4) {
+        if ((mode == MODE_CONV || mode == MODE_MAXPOOL) && P <= 1024) {
+            if (mode == MODE_CONV && !aligned16(out)) return fail(XGPR_ERR_WORKSPACE, "output pointer must be 16-byte aligned");
+            if (!workspace || wbytes < masks_bytes(R)) return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_rbf_workspace_bytes)");
+            WaveArgs a = {};
+            a.x = x; a.out = out; a.outf = outf; a.masks = (const uint64_t *)workspace; a.chi = chi; a.seqlen = seqlen_dev;
+            a.n = n; a.row_stride = L * C; a.F = num_freqs; a.d = (int)win; a.kmer_stride = (int)C;
+            a.conv_width = conv_width; a.scaling_type = scaling_type;
+            a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
+            a.scale = sqrt(1.0 / (double)num_freqs);
+            const int lg = ilog2(P);
+            fill_norms(a, lg);
+            rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
+            if (rc) return rc;
+            const long nblocks = (n * a.nb + 3) / 4;
+            if (nblocks > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
+            if (mode == MODE_CONV) {
+#define CALL_CONV(LG) hipLaunchKernelGGL((wave_conv_kernel<LG, false>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
+                DISPATCH_LOG2P(lg, CALL_CONV)
+#undef CALL_CONV
+            } else {
+#define CALL_MAXP(LG) hipLaunchKernelGGL((wave_conv_kernel<LG, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
+                DISPATCH_LOG2P(lg, CALL_MAXP)
+#undef CALL_MAXP
+            }
+            HIP_TRY(hipGetLastError(), "wave_conv_kernel launch");
+            return 0;
+        }
+    }
+    SorfArgs<T> a = {};
+    a.x = x; a.out = out; a.grad = grad; a.outf = outf; a.radem = radem; a.chi = chi; a.seqlen = seqlen_dev;
+    a.n = n; a.row_stride = L * C; a.F = num_freqs; a.R = R; a.d = (int)win; a.kmer_stride = (int)C;
+    a.conv_width = conv_width; a.P = (int)P; a.reps = reps; a.scaling_type = scaling_type;
+    a.nc = norm_constant<T>(P); a.scale = sqrt(1.0 / (double)num_freqs); a.sigma = sigma;
+    if (mode == MODE_CONV) return launch_generic_sorf<T, MODE_CONV>(a, st);
+    if (mode == MODE_CONV_GRAD) return launch_generic_sorf<T, MODE_CONV_GRAD>(a, st);
+    return launch_generic_sorf<T, MODE_MAXPOOL>(a, st);
+}
+
+constexpr long ZTZ_MAX_SLABS = 1024;
+
+template <bool MATVEC>
+int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double *vec, double *w_out, long n,
+             long d, long num_rffs, long num_freqs, long R, int fit_intercept, void *workspace, size_t wbytes,
+             void *stream) {
+    const long P = padded_width(d);
+    if (n == 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (num_rffs < 2 || (num_rffs & 1) != 0) return fail(XGPR_ERR_ODD_OUTPUT, "last dim of output must be even number");
+    if (2 * num_freqs != num_rffs || num_freqs > R) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    if (R % P != 0) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    if (P > 1024) return fail(XGPR_ERR_UNSUPPORTED, "fused matvec supports padded width <= 1024");
+    if (num_freqs > 8192) return fail(XGPR_ERR_UNSUPPORTED, "fused matvec supports num_freqs <= 8192");
+    if ((MATVEC && !aligned16(vec)) || !aligned16(w_out)) return fail(XGPR_ERR_WORKSPACE, "vector pointers must be 16-byte aligned");
+    const size_t mb = masks_bytes(R);
+    const size_t need = mb + (size_t)ZTZ_MAX_SLABS * num_rffs * sizeof(double);
+    if (!workspace || wbytes < need || !aligned16(workspace))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_ztz_matvec_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+
+    WaveArgs a = {};
+    a.x = x; a.masks = (const uint64_t *)workspace; a.chi = chi; a.vec = vec;
+    a.wpart = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(workspace) + mb);
+    a.n = n; a.row_stride = d; a.F = num_freqs; a.d = (int)d;
+    a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
+    a.G = a.nb >= 4 ? 1 : 4 / a.nb;
+    a.fit_intercept = fit_intercept;
+    a.scale = rbf_scale<float>(num_freqs, fit_intercept);
+    const int lg = ilog2(P);
+    fill_norms(a, lg);
+    int rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
+    if (rc) return rc;
+
+    const int waves_per_wg = a.nb * a.G;
+    const int wg_per_cu = waves_per_wg <= 4 ? 2 : 1;     // 2 waves per SIMD
+    long nblocks = (long)device_cus() * wg_per_cu;
+    const long max_by_rows = (n + a.G - 1) / a.G;
+    if (nblocks > max_by_rows) nblocks = max_by_rows;
+    if (nblocks * a.G > ZTZ_MAX_SLABS) nblocks = ZTZ_MAX_SLABS / a.G;
+    const long nslabs = nblocks * a.G;
+#define CALL_ZTZ(LG) hipLaunchKernelGGL((wave_ztz_kernel<LG, MATVEC>), dim3((unsigned)nblocks), dim3(waves_per_wg * 64), 0, st, a)
+    DISPATCH_LOG2P(lg, CALL_ZTZ)
+#undef CALL_ZTZ
+    HIP_TRY(hipGetLastError(), "wave_ztz_kernel launch");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((num_rffs + 63) / 64)), dim3(256), 0, st, a.wpart, w_out,
+                       num_rffs, nslabs);
+    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+const char *xgpr_last_error(void) { return g_err.c_str(); }
+const char *xgpr_build_arch(void) { return "gfx950"; }
+
+int xgpr_fht_f32(float *x, long n, long dim1, long dim2, void *stream) { return fht_impl<float>(x, n, dim1, dim2, stream); }
+int xgpr_fht_f64(double *x, long n, long dim1, long dim2, void *stream) { return fht_impl<double>(x, n, dim1, dim2, stream); }
+
+int xgpr_srht_f32(float *x, const int8_t *radem, long n, long dim, long radem_len, void *stream) {
+    return srht_impl<float>(x, radem, n, dim, radem_len, stream);
+}
+int xgpr_srht_f64(double *x, const int8_t *radem, long n, long dim, long radem_len, void *stream) {
+    return srht_impl<double>(x, radem, n, dim, radem_len, stream);
+}
+
+size_t xgpr_rbf_workspace_bytes(long radem_shape2) { return masks_bytes(radem_shape2); }
+
+int xgpr_rbf_feature_gen_f32(const float *x, double *out, const int8_t *radem, const float *chi, long n, long d,
+                             long out_rows, long num_rffs, long num_freqs, long radem_shape2, int fit_intercept,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    return rbf_impl<float>(x, out, nullptr, radem, chi, n, d, out_rows, num_rffs, 0, 0, num_freqs, radem_shape2, 0.0,
+                           fit_intercept, false, workspace, workspace_bytes, stream);
+}
+int xgpr_rbf_feature_gen_f64(const double *x, double *out, const int8_t *radem, const double *chi, long n, long d,
+                             long out_rows, long num_rffs, long num_freqs, long radem_shape2, int fit_intercept,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    return rbf_impl<double>(x, out, nullptr, radem, chi, n, d, out_rows, num_rffs, 0, 0, num_freqs, radem_shape2, 0.0,
+                            fit_intercept, false, workspace, workspace_bytes, stream);
+}
+int xgpr_rbf_grad_f32(const float *x, double *out, double *grad, const int8_t *radem, const float *chi, long n,
+                      long d, long out_rows, long num_rffs, long grad_rows, long grad_cols, long num_freqs,
+                      long radem_shape2, double sigma, int fit_intercept, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    return rbf_impl<float>(x, out, grad, radem, chi, n, d, out_rows, num_rffs, grad_rows, grad_cols, num_freqs,
+                           radem_shape2, sigma, fit_intercept, true, workspace, workspace_bytes, stream);
+}
+int xgpr_rbf_grad_f64(const double *x, double *out, double *grad, const int8_t *radem, const double *chi, long n,
+                      long d, long out_rows, long num_rffs, long grad_rows, long grad_cols, long num_freqs,
+                      long radem_shape2, double sigma, int fit_intercept, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    return rbf_impl<double>(x, out, grad, radem, chi, n, d, out_rows, num_rffs, grad_rows, grad_cols, num_freqs,
+                            radem_shape2, sigma, fit_intercept, true, workspace, workspace_bytes, stream);
+}
+
+int xgpr_conv1d_fgen_f32(const float *x, double *out, const int8_t *radem, const float *chi,
+                         const int32_t *seqlen_host, const int32_t *seqlen_dev, long n, long L, long C,
+                         long out_rows, long num_rffs, long num_freqs, long radem_shape2, long nseq, int conv_width,
+                         int scaling_type, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_impl<float>(x, out, nullptr, nullptr, radem, chi, seqlen_host, seqlen_dev, n, L, C, out_rows, num_rffs,
+                            0, 0, num_freqs, radem_shape2, nseq, 0.0, conv_width, scaling_type, MODE_CONV, workspace,
+                            workspace_bytes, stream);
+}
+int xgpr_conv1d_fgen_f64(const double *x, double *out, const int8_t *radem, const double *chi,
+                         const int32_t *seqlen_host, const int32_t *seqlen_dev, long n, long L, long C,
+                         long out_rows, long num_rffs, long num_freqs, long radem_shape2, long nseq, int conv_width,
+                         int scaling_type, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_impl<double>(x, out, nullptr, nullptr, radem, chi, seqlen_host, seqlen_dev, n, L, C, out_rows,
+                             num_rffs, 0, 0, num_freqs, radem_shape2, nseq, 0.0, conv_width, scaling_type, MODE_CONV,
+                             workspace, workspace_bytes, stream);
+}
+int xgpr_conv_grad_f32(const float *x, double *out, double *grad, const int8_t *radem, const float *chi,
+                       const int32_t *seqlen_host, const int32_t *seqlen_dev, long n, long L, long C, long out_rows,
+                       long num_rffs, long grad_rows, long grad_cols, long num_freqs, long radem_shape2, long nseq,
+                       double sigma, int conv_width, int scaling_type, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+    return conv_impl<float>(x, out, grad, nullptr, radem, chi, seqlen_host, seqlen_dev, n, L, C, out_rows, num_rffs,
+                            grad_rows, grad_cols, num_freqs, radem_shape2, nseq, sigma, conv_width, scaling_type,
+                            MODE_CONV_GRAD, workspace, workspace_bytes, stream);
+}
+int xgpr_conv_grad_f64(const double *x, double *out, double *grad, const int8_t *radem, const double *chi,
+                       const int32_t *seqlen_host, const int32_t *seqlen_dev, long n, long L, long C, long out_rows,
+                       long num_rffs, long grad_rows, long grad_cols, long num_freqs, long radem_shape2, long nseq,
+                       double sigma, int conv_width, int scaling_type, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+    return conv_impl<double>(x, out, grad, nullptr, radem, chi, seqlen_host, seqlen_dev, n, L, C, out_rows, num_rffs,
+                             grad_rows, grad_cols, num_freqs, radem_shape2, nseq, sigma, conv_width, scaling_type,
+                             MODE_CONV_GRAD, workspace, workspace_bytes, stream);
+}
+int xgpr_conv1d_maxpool_f32(const float *x, float *out, const int8_t *radem, const float *chi,
+                            const int32_t *seqlen_host, const int32_t *seqlen_dev, long n, long L, long C,
+                            long out_rows, long num_rffs, long num_freqs, long radem_shape2, long nseq,
+                            int conv_width, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_impl<float>(x, nullptr, nullptr, out, radem, chi, seqlen_host, seqlen_dev, n, L, C, out_rows, num_rffs,
+                            0, 0, num_freqs, radem_shape2, nseq, 0.0, conv_width, 0, MODE_MAXPOOL, workspace,
+                            workspace_bytes, stream);
+}
+int xgpr_conv1d_maxpool_f64(const double *x, float *out, const int8_t *radem, const double *chi,
+                            const int32_t *seqlen_host, const int32_t *seqlen_dev, long n, long L, long C,
+                            long out_rows, long num_rffs, long num_freqs, long radem_shape2, long nseq,
+                            int conv_width, void *workspace, size_t workspace_bytes, void *stream) {
+    return conv_impl<double>(x, nullptr, nullptr, out, radem, chi, seqlen_host, seqlen_dev, n, L, C, out_rows,
+                             num_rffs, 0, 0, num_freqs, radem_shape2, nseq, 0.0, conv_width, 0, MODE_MAXPOOL,
+                             workspace, workspace_bytes, stream);
+}
+
+size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2) {
+    return masks_bytes(radem_shape2) + (size_t)ZTZ_MAX_SLABS * num_rffs * sizeof(double);
+}
+int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v, double *w_out,
+                        long n, long d, long num_rffs, long num_freqs, long radem_shape2, int fit_intercept,
+                        void *workspace, size_t workspace_bytes, void *stream) {
+    return ztz_impl<true>(x, radem, chi, v, w_out, n, d, num_rffs, num_freqs, radem_shape2, fit_intercept, workspace,
+                          workspace_bytes, stream);
+}
+int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const double *y, double *zty_out, long n,
+                 long d, long num_rffs, long num_freqs, long radem_shape2, int fit_intercept, void *workspace,
+                 size_t workspace_bytes, void *stream) {
+    return ztz_impl<false>(x, radem, chi, y, zty_out, n, d, num_rffs, num_freqs, radem_shape2, fit_intercept, workspace,
+                           workspace_bytes, stream);
+}
+
+int xgpr_selftest_lane_xor(int32_t *out, void *stream) {
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+    HIP_TRY(hipGetLastError(), "selftest_kernel launch");
+    return 0;
+}
+
+}  // extern "C"

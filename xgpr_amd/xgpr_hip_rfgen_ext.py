@@ -1,0 +1,238 @@
+"""Operator surface of the reference's GPU extension module, served by libxgpr_hip.so.
+
+Mirrors ``xGPR.xgpr_cuda_rfgen_cpp_ext`` (reference:
+src/xGPR/random_feature_generation/gpu_rf_gen/xgpr_cuda_rfgen_cpp_ext.cpp:20-93): same
+function names (``cuda*`` kept as aliases of the ``hip*`` names), same keyword names, same
+in-place semantics, same error behaviour -- arguments are *not* converted (wrong dtype,
+device or contiguity raises ``TypeError`` like nanobind's ``.noconvert()``), validation
+failures raise ``RuntimeError`` with the reference's messages, and every function returns 0.
+
+Arrays are ``torch`` tensors on the HIP device (the reference takes cupy arrays; cupy is
+not part of this image).  ``seqlengths`` stays on the HOST (int32 numpy array or CPU
+tensor), as in the reference's CUDA module (gpu_rf_gen/convolution_ops/rbf_convolution.h:19).
+Calls are asynchronous on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_LIB = _lib.load()
+
+_T2S = {torch.float32: "f32", torch.float64: "f64"}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype, ndim):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch tensor on the HIP device")
+    if not t.is_cuda:
+        raise TypeError(f"{name}: expected a device tensor, got a host tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() != ndim:
+        raise TypeError(f"{name}: expected {ndim} dims, got {t.dim()}")
+    if not t.is_contiguous():
+        raise TypeError(f"{name}: expected a C-contiguous array")
+    return C.c_void_p(t.data_ptr())
+
+
+def _ftype(t, name):
+    if not isinstance(t, torch.Tensor) or t.dtype not in _T2S:
+        raise TypeError(f"{name}: expected a float32 or float64 torch tensor")
+    return _T2S[t.dtype]
+
+
+def _workspace(nbytes, device):
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    return ws, C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel())
+
+
+def _seqlens(seqlengths, device):
+    """Host int32 array (validated by the library on the host) + its device copy."""
+    if isinstance(seqlengths, torch.Tensor):
+        if seqlengths.is_cuda or seqlengths.dtype != torch.int32 or seqlengths.dim() != 1:
+            raise TypeError("seqlengths: expected a 1-d int32 array on the host")
+        host = seqlengths.contiguous().numpy()
+    elif isinstance(seqlengths, np.ndarray):
+        if seqlengths.dtype != np.int32 or seqlengths.ndim != 1 or not seqlengths.flags["C_CONTIGUOUS"]:
+            raise TypeError("seqlengths: expected a C-contiguous 1-d int32 array on the host")
+        host = seqlengths
+    else:
+        raise TypeError("seqlengths: expected a numpy array or CPU tensor (int32)")
+    dev = torch.from_numpy(host).to(device, non_blocking=False)
+    return host, dev
+
+
+def hipFastHadamardTransform2D(inputArr):
+    """In-place un-normalised FHT over the last axis of a 2-d array
+    (cudaFastHadamardTransform2D, xgpr_cuda_rfgen_cpp_ext.cpp:21-24)."""
+    s = _ftype(inputArr, "inputArr")
+    p = _dev(inputArr, "inputArr", None, 2)
+    return _lib.check(getattr(_LIB, f"xgpr_fht_{s}")(p, inputArr.shape[0], 1, inputArr.shape[1], _stream()))
+
+
+def hipFastHadamardTransform(inputArr):
+    """3-d form (cpuFastHadamardTransform, cpu_rf_gen/xgpr_cpu_rfgen_cpp_ext.cpp:24-30)."""
+    s = _ftype(inputArr, "inputArr")
+    p = _dev(inputArr, "inputArr", None, 3)
+    return _lib.check(getattr(_LIB, f"xgpr_fht_{s}")(p, inputArr.shape[0], inputArr.shape[1],
+                                                      inputArr.shape[2], _stream()))
+
+
+def hipSRHT(inputArr, radem):
+    """cudaSRHT (xgpr_cuda_rfgen_cpp_ext.cpp:25-30)."""
+    s = _ftype(inputArr, "inputArr")
+    p = _dev(inputArr, "inputArr", None, 2)
+    r = _dev(radem, "radem", torch.int8, 1)
+    return _lib.check(getattr(_LIB, f"xgpr_srht_{s}")(p, r, inputArr.shape[0], inputArr.shape[1],
+                                                       radem.shape[0], _stream()))
+
+
+def _radem3(radem):
+    r = _dev(radem, "radem", torch.int8, 3)
+    if radem.shape[0] != 3 or radem.shape[1] != 1:
+        raise TypeError("radem: expected shape (3, 1, R)")
+    return r
+
+
+def hipRBFFeatureGen(inputArr, outputArr, radem, chiArr, fitIntercept):
+    """cudaRBFFeatureGen (xgpr_cuda_rfgen_cpp_ext.cpp:32-40).  The output is overwritten
+    (as by the reference's CUDA kernel, rbf_ops.cu:121-127)."""
+    s = _ftype(inputArr, "inputArr")
+    x = _dev(inputArr, "inputArr", None, 2)
+    o = _dev(outputArr, "outputArr", torch.float64, 2)
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
+    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    return _lib.check(getattr(_LIB, f"xgpr_rbf_feature_gen_{s}")(
+        x, o, r, c, inputArr.shape[0], inputArr.shape[1], outputArr.shape[0], outputArr.shape[1],
+        chiArr.shape[0], radem.shape[2], int(bool(fitIntercept)), wp, wn, _stream()))
+
+
+def hipRBFGrad(inputArr, outputArr, gradArr, radem, chiArr, sigma, fitIntercept):
+    """cudaRBFGrad (xgpr_cuda_rfgen_cpp_ext.cpp:41-49)."""
+    s = _ftype(inputArr, "inputArr")
+    x = _dev(inputArr, "inputArr", None, 2)
+    o = _dev(outputArr, "outputArr", torch.float64, 2)
+    g = _dev(gradArr, "gradArr", torch.float64, 3)
+    if gradArr.shape[2] != 1:
+        raise TypeError("gradArr: expected shape (N, M, 1)")
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
+    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    return _lib.check(getattr(_LIB, f"xgpr_rbf_grad_{s}")(
+        x, o, g, r, c, inputArr.shape[0], inputArr.shape[1], outputArr.shape[0], outputArr.shape[1],
+        gradArr.shape[0], gradArr.shape[1], chiArr.shape[0], radem.shape[2], float(sigma),
+        int(bool(fitIntercept)), wp, wn, _stream()))
+
+
+def hipConv1dFGen(inputArr, outputArr, radem, chiArr, seqlengths, convWidth, scalingType):
+    """cudaConv1dFGen (xgpr_cuda_rfgen_cpp_ext.cpp:70-80); results are added into outputArr."""
+    s = _ftype(inputArr, "inputArr")
+    x = _dev(inputArr, "inputArr", None, 3)
+    o = _dev(outputArr, "outputArr", torch.float64, 2)
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
+    host, dev = _seqlens(seqlengths, inputArr.device)
+    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    return _lib.check(getattr(_LIB, f"xgpr_conv1d_fgen_{s}")(
+        x, o, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
+        inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], chiArr.shape[0],
+        radem.shape[2], host.shape[0], int(convWidth), int(scalingType), wp, wn, _stream()))
+
+
+def hipConvGrad(inputArr, outputArr, radem, chiArr, seqlengths, gradArr, sigma, convWidth, scalingType):
+    """cudaConvGrad (xgpr_cuda_rfgen_cpp_ext.cpp:81-92)."""
+    s = _ftype(inputArr, "inputArr")
+    x = _dev(inputArr, "inputArr", None, 3)
+    o = _dev(outputArr, "outputArr", torch.float64, 2)
+    g = _dev(gradArr, "gradArr", torch.float64, 3)
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
+    host, dev = _seqlens(seqlengths, inputArr.device)
+    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    return _lib.check(getattr(_LIB, f"xgpr_conv_grad_{s}")(
+        x, o, g, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
+        inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], gradArr.shape[0],
+        gradArr.shape[1], chiArr.shape[0], radem.shape[2], host.shape[0], float(sigma), int(convWidth),
+        int(scalingType), wp, wn, _stream()))
+
+
+def hipConv1dMaxpool(inputArr, outputArr, radem, chiArr, seqlengths, convWidth):
+    """cudaConv1dMaxpool (xgpr_cuda_rfgen_cpp_ext.cpp:61-69); float32 output."""
+    s = _ftype(inputArr, "inputArr")
+    x = _dev(inputArr, "inputArr", None, 3)
+    o = _dev(outputArr, "outputArr", torch.float32, 2)
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
+    host, dev = _seqlens(seqlengths, inputArr.device)
+    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    return _lib.check(getattr(_LIB, f"xgpr_conv1d_maxpool_{s}")(
+        x, o, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
+        inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], chiArr.shape[0],
+        radem.shape[2], host.shape[0], int(convWidth), wp, wn, _stream()))
+
+
+def hipZtZMatvec(inputArr, radem, chiArr, vec, outVec, fitIntercept, workspace=None):
+    """Fused ``Z.T @ (Z @ vec)`` over one shard of (sigma-scaled, float32) rows: the chunk
+    body of the reference's CG matvec (fitting_toolkit/cg_tools.py:189-191) with
+    ``kernel.transform_x`` fused in.  ``outVec`` [num_rffs] f64 is overwritten."""
+    x = _dev(inputArr, "inputArr", torch.float32, 2)
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", torch.float32, 1)
+    v = _dev(vec, "vec", torch.float64, 1)
+    o = _dev(outVec, "outVec", torch.float64, 1)
+    if vec.shape[0] != outVec.shape[0]:
+        raise TypeError("vec / outVec: shapes differ")
+    need = _LIB.xgpr_ztz_matvec_workspace_bytes(outVec.shape[0], radem.shape[2])
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=inputArr.device)
+    return _lib.check(_LIB.xgpr_ztz_matvec_f32(
+        x, r, c, v, o, inputArr.shape[0], inputArr.shape[1], outVec.shape[0], chiArr.shape[0],
+        radem.shape[2], int(bool(fitIntercept)), C.c_void_p(workspace.data_ptr()),
+        C.c_size_t(workspace.numel()), _stream()))
+
+
+def hipZtY(inputArr, radem, chiArr, yvec, outVec, fitIntercept, workspace=None):
+    """Fused ``Z.T @ y`` over one shard (scoring_toolkit/exact_nmll_calcs.py:35-37)."""
+    x = _dev(inputArr, "inputArr", torch.float32, 2)
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", torch.float32, 1)
+    y = _dev(yvec, "yvec", torch.float64, 1)
+    o = _dev(outVec, "outVec", torch.float64, 1)
+    if yvec.shape[0] != inputArr.shape[0]:
+        raise TypeError("yvec: one value per datapoint expected")
+    need = _LIB.xgpr_ztz_matvec_workspace_bytes(outVec.shape[0], radem.shape[2])
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=inputArr.device)
+    return _lib.check(_LIB.xgpr_zty_f32(
+        x, r, c, y, o, inputArr.shape[0], inputArr.shape[1], outVec.shape[0], chiArr.shape[0],
+        radem.shape[2], int(bool(fitIntercept)), C.c_void_p(workspace.data_ptr()),
+        C.c_size_t(workspace.numel()), _stream()))
+
+
+def ztz_workspace_bytes(num_rffs, radem_shape2):
+    return int(_LIB.xgpr_ztz_matvec_workspace_bytes(num_rffs, radem_shape2))
+
+
+def selftest_lane_xor(device="cuda"):
+    """Runs the cross-lane butterfly self test; returns an int32 [6, 16, 64] CPU array."""
+    out = torch.zeros(6 * 16 * 64, dtype=torch.int32, device=device)
+    _lib.check(_LIB.xgpr_selftest_lane_xor(C.c_void_p(out.data_ptr()), _stream()))
+    return out.cpu().numpy().reshape(6, 16, 64)
+
+
+# the reference's names, so that its kernel classes / tests can bind to this module unchanged
+cudaFastHadamardTransform2D = hipFastHadamardTransform2D
+cudaSRHT = hipSRHT
+cudaRBFFeatureGen = hipRBFFeatureGen
+cudaRBFGrad = hipRBFGrad
+cudaConv1dMaxpool = hipConv1dMaxpool
+cudaConv1dFGen = hipConv1dFGen
+cudaConvGrad = hipConvGrad
