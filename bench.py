@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of the hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+Matern-5/2 kernel, N = 1e6 datapoints, d = 1024, 8192 random features, rows sharded
+contiguously over the ranks (STRONG scaling: N is the whole job), rank-512 randomized-Nystrom
+preconditioner.  Synthetic data (X ~ N(0,1)/sqrt(d) from the device RNG, seeded per rank;
+y = sin(X a) + 0.1 eps), resident in HBM before the timed region.
+
+A "step" is one preconditioned-CG iteration (reference fitting_toolkit/cg_tools.py:255-287):
+one pass of the fused feature-generation + Z^T(Z p) kernel over all N rows (every iteration
+regenerates all N x M random features; Z is never written), the RCCL all-reduce of w, the
+preconditioner apply and the float64 vector updates, including the per-iteration convergence
+check.  value = N * M * K / t  random features per second (whole job); cg_iters_per_sec = K / t.
+
+Besides the contract fields the JSON line carries
+  roofline      -- the dominant kernel (wave_ztz_kernel): algorithmic HBM bytes (4*d per row)
+                   over its measured duration (HIP events on the launch stream)
+  featgen_op    -- the stand-alone cudaRBFFeatureGen-equivalent operator (Z materialised as
+                   float64), with its own HBM roofline (4*d + 8*M bytes per row)
+  cpu_baseline  -- the CPU oracle (OpenMP port of the reference CPU algorithm) timed on this
+                   box's host cores on a bounded row sample (rank 0, --gpus 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="N, total over all ranks")
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--rffs", type=int, default=8192)
+    ap.add_argument("--rank-precond", type=int, default=512)
+    ap.add_argument("--precond-rows", type=int, default=32768,
+                    help="rows (total) the preconditioner is built from, outside the timed region")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="CPU-baseline budget: whole 8192-row chunks are processed until this much time is spent")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_shard(n_local, d, rank, device):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(123 + 1000 * rank)
+    x = torch.randn((n_local, d), generator=gen, device=device, dtype=torch.float32) / np.sqrt(d)
+    ga = torch.Generator(device=device)
+    ga.manual_seed(7)
+    a = torch.randn(d, generator=ga, device=device, dtype=torch.float32) * 3.0
+    y = torch.sin(x @ a).double() + 0.1 * torch.randn(n_local, generator=gen, device=device, dtype=torch.float64)
+    return x, y
+
+
+def cpu_baseline(args, budget_s):
+    """The reference CPU algorithm (oracle/: C + OpenMP restatement, pinned against the
+    reference) on a bounded sample of the same workload: feature generation + Z^T(Z p) per
+    8192-row chunk, as fitting_toolkit/cg_tools.py:189-191 does."""
+    from oracle import oracle as orc
+    orc.build(ref=False)
+    ops = orc.Oracle()
+    rng = np.random.default_rng(5)
+    d, m = args.dim, args.rffs
+    radem, chi = orc.draw_sorf_params(m, d, 123)
+    orc.matern_rescale(chi, 2.5, 123)
+    p = rng.standard_normal(m)
+    chunk = 8192
+    x = (rng.standard_normal((chunk, d)) / np.sqrt(d)).astype(np.float32)
+    z = np.zeros((chunk, m))
+    w = np.zeros(m)
+    ops.cpuRBFFeatureGen(x, z, radem, chi, True)       # warm-up (page in, thread pool)
+    t_feat = t_mv = 0.0
+    done = 0
+    while (t_feat + t_mv) < budget_s and done < args.rows:
+        z[:] = 0
+        t0 = time.perf_counter()
+        ops.cpuRBFFeatureGen(x, z, radem, chi, True)
+        z[:, 0] = 1.0
+        t1 = time.perf_counter()
+        ops.ztz_matvec(z, p, w)
+        t2 = time.perf_counter()
+        t_feat += t1 - t0
+        t_mv += t2 - t1
+        done += chunk
+    return {
+        "value": done * m / (t_feat + t_mv), "unit": "random-features/s",
+        "cores": ops.num_threads(), "kind": "port",
+        "sample": f"{done} rows of the same workload (d={d}, M={m}) in {chunk}-row chunks: "
+                  f"feature-gen {t_feat:.2f} s + Z^T(Zp) {t_mv:.2f} s; scaled linearly in rows",
+        "featgen_only_features_per_s": done * m / t_feat,
+        "cg_iters_per_sec_extrapolated": 1.0 / ((t_feat + t_mv) * args.rows / done),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    from xgpr_amd import dist as xd
+    comm = xd.init_from_env(device_type="cuda")
+    if comm.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={comm.world_size}: launch with torch.distributed.run")
+    device = torch.device("cuda", torch.cuda.current_device())
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import DeviceDataset, build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import ConjugateGrad, calc_zty
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+
+    n, d, m = args.rows, args.dim, args.rffs
+    lo, hi = comm.shard_bounds(n)
+    x, y = make_shard(hi - lo, d, comm.rank, device)
+    ds = build_regression_dataset(x, y, chunk_size=16384, device=device, comm=comm, already_sharded=True)
+    kern = make_kernel("Matern", (n, d), m, 123, device, {"matern_nu": 5 / 2})
+    kern.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+
+    # preconditioner from a row subsample (its quality does not change the cost of a CG step)
+    sub = max(args.rank_precond + 1, args.precond_rows // comm.world_size)
+    sub = min(sub, hi - lo)
+    ds_sub = DeviceDataset(x[:sub], y[:sub], None, 8192, ds.get_ymean(), ds.get_ystd(),
+                           sub * comm.world_size, device, comm)
+    pre = RandNysPreconditioner(kern, ds_sub, args.rank_precond, False, 123, "srht")
+    zty, _ = calc_zty(ds, kern)
+
+    cg = ConjugateGrad(comm)
+    timings = []
+
+    # wrap the fused matvec with HIP events on the launch stream (torch's current stream)
+    orig = kern.ztz_matvec
+
+    def timed_matvec(xs, vec, out, ws=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(xs, vec, out, ws)
+        e1.record()
+        timings.append((e0, e1))
+    kern.ztz_matvec = timed_matvec
+
+    def run(iters):
+        resid = torch.zeros((m, 2, 1), dtype=torch.float64, device=device)
+        resid[:, 0, 0] = zty / n
+        return cg.fit(ds, kern, pre, resid, maxiter=iters, tol=0.0, verbose=False)
+
+    if args.warmup > 0:
+        run(args.warmup)
+    timings.clear()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, _, niter, losses = run(args.steps)
+    torch.cuda.synchronize()
+    comm.barrier()
+    t1 = time.perf_counter()
+    assert niter == args.steps
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    if comm.world_size > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    t = float(elapsed.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in timings]))
+    kern.ztz_matvec = orig
+
+    # stand-alone feature-generation operator (Z materialised, float64), this rank's device
+    fg_rows = min(16384, hi - lo)
+    xs = ds.scaled_x(1.0)[:fg_rows]
+    zbuf = torch.empty((fg_rows, m), dtype=torch.float64, device=device)
+    for _ in range(2):
+        ext.hipRBFFeatureGen(xs, zbuf, kern.radem_diag, kern.chi_arr, True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        ext.hipRBFFeatureGen(xs, zbuf, kern.radem_diag, kern.chi_arr, True)
+    e1.record()
+    torch.cuda.synchronize()
+    fg_ms = e0.elapsed_time(e1) / reps
+    del zbuf
+
+    if comm.rank == 0:
+        n_local = hi - lo
+        alg_bytes = 4.0 * d * n_local                   # 4*d bytes per row, X read once
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        fg_bytes = (4.0 * d + 8.0 * m) * fg_rows
+        fg_gbs = fg_bytes / (fg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "random-features/sec (fused CG matvec; every CG iteration regenerates all N x M features)",
+            "value": n * m * args.steps / t,
+            "unit": "random-features/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t / args.steps,
+            "cg_iters_per_sec": args.steps / t,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 (SORF + cos/sin) / f64 (Z^T Z p accumulation and CG state)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Matern-5/2, N=%d, d=%d, %d RFFs, rows sharded over %d GPU(s), "
+                                   "rank-%d SRHT preconditioner (built from %d rows), CG step" %
+                                   (n, d, m, args.gpus, args.rank_precond, sub * comm.world_size),
+                       "rows_per_gpu": n_local, "lambda": 0.1, "sigma": 1.0},
+            "roofline": {"kernel": "wave_ztz_kernel<10, true> (+ pack_radem, reduce_slabs)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": kern_ms,
+                         "note": "HBM traffic of this kernel is only the X read; the binding resource is VALU "
+                                 "(butterflies + sincos), see DESIGN.md"},
+            "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
+                           "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},
+            "final_loss": losses[-1],
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if comm.world_size > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

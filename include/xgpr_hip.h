@@ -64,6 +64,12 @@ int xgpr_srht_f64(double *x, const int8_t *radem, long n, long dim, long radem_l
  * chi[num_freqs] (T).  Like the reference's CUDA kernel (rbf_ops.cu:121-127) the output
  * is OVERWRITTEN: out[i, 2f] = s*cos(chi[f]*sorf(x_i)[f]), out[i, 2f+1] = s*sin(...). */
 size_t xgpr_rbf_workspace_bytes(long radem_shape2);
+/* Workspace for any SORF operator below (feature-gen, grad, conv, max-pool): covers the
+ * packed sign masks of the float fast path (padded width <= 1024) and, for padded widths
+ * beyond the LDS capacity (> 32768 float / > 16384 double), the global scratch of the
+ * generic path.  `width` is the un-padded transform width (d, or conv_width * C);
+ * elem_size is sizeof(T). */
+size_t xgpr_sorf_workspace_bytes(long radem_shape2, long width, int elem_size);
 int xgpr_rbf_feature_gen_f32(const float *x, double *out, const int8_t *radem, const float *chi,
                              long n, long d, long out_rows, long num_rffs, long num_freqs,
                              long radem_shape2, int fit_intercept,

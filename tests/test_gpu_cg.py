@@ -1,0 +1,106 @@
+"""GPU parity of the solver side of the path -- transform_x, z^T y, the randomized-Nystrom
+preconditioner and preconditioned CG -- against the values the REFERENCE's own Python
+produced (tests/golden/g7_cg.npz: BASELINE cfg1-sized problem; g8_e2e.npz: the reference's
+381x84 fixture with the settings of its tests/fitting_tests/test_cg_fit.py:26-40).
+Bar (BASELINE.json north_star): CG iterates within 1e-5 relative; iteration counts equal."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("kname,parms", [("RBF", {}), ("Matern", {"matern_nu": 5 / 2})])
+def test_g7_cg_iterates(kname, parms):
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import cg_fit_lib_internal, calc_zty
+    g = load_golden("g7_cg.npz")
+    x, y = g["x"], g["y"]
+    ds = build_regression_dataset(x, y, chunk_size=int(g["chunk_size"]), device=DEV)
+    assert np.isclose(ds.get_ymean(), float(g["y_mean"]), rtol=1e-12)
+    assert np.isclose(ds.get_ystd(), float(g["y_std"]), rtol=1e-12)
+    kern = make_kernel(kname, x.shape, int(g["num_rffs"]), 123, DEV, parms)
+    kern.set_hyperparams(g["hyperparams"], logspace=False)
+    z8 = kern.transform_x(x[:8]).cpu().numpy()
+    scale = np.sqrt(1.0 / (kern.num_freqs - 0.5))
+    assert np.abs(z8 - g[f"{kname}_z_first8"]).max() <= 4e-7 * scale
+    zty, yty = calc_zty(ds, kern)          # fused z^T y kernel
+    assert rel(zty, g[f"{kname}_zty"]) < 1e-6
+    assert np.isclose(yty, float(g[f"{kname}_yty"]), rtol=1e-10)
+    for ptag, method in [("none", None), ("srht", "srht"), ("srht2", "srht_2")]:
+        pre = None
+        if method is not None:
+            pre = RandNysPreconditioner(kern, ds, 64, False, 123, method)
+            assert np.allclose(pre.eig.cpu().numpy(), g[f"{kname}_{ptag}_eig"], rtol=1e-5)
+            assert np.isclose(pre.achieved_ratio, float(g[f"{kname}_{ptag}_ratio"]), rtol=1e-4)
+            assert rel(pre.get_zty(), g[f"{kname}_{ptag}_zty"]) < 1e-6
+            u_ref = g[f"{kname}_{ptag}_u"]
+            v = np.linspace(-1, 1, u_ref.shape[0])
+            pu = (pre.u_mat @ (pre.u_mat.T @ torch.from_numpy(v).to(DEV))).cpu().numpy()
+            assert np.allclose(pu, u_ref @ (u_ref.T @ v), atol=1e-5)
+        ref_it = g[f"{kname}_{ptag}_iterates"]
+        trace = {}
+        w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-30, ref_it.shape[0], pre, False, trace=trace)
+        n = ds.get_ndatapoints()
+        for j in range(ref_it.shape[0]):
+            got = trace["x_k"][j][:, 0].cpu().numpy() * n
+            assert np.linalg.norm(got - ref_it[j]) <= 1e-5 * np.linalg.norm(ref_it[j]), (ptag, j)
+        nl = min(len(losses), len(g[f"{kname}_{ptag}_losses"]))
+        assert np.allclose(losses[:nl], g[f"{kname}_{ptag}_losses"][:nl], rtol=1e-4)
+        # full solve to the reference's tolerance: same iteration count, same weights
+        w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False)
+        assert abs(niter - int(g[f"{kname}_{ptag}_niter"])) <= 1, (ptag, niter)
+        assert rel(w, g[f"{kname}_{ptag}_weights"]) < 1e-5
+
+
+def test_g8_reference_fixture_end_to_end():
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import cg_fit_lib_internal
+    g = load_golden("g8_e2e.npz")
+    x, y = g["xtrain"], g["ytrain"]
+    ds = build_regression_dataset(x, y, chunk_size=2000, device=DEV)
+    kern = make_kernel("RBF", x.shape, 4096, 123, DEV, {"intercept": True})
+    kern.set_hyperparams(g["hparam_log"], logspace=True)
+    pre = RandNysPreconditioner(kern, ds, 256, False, 123, "srht")
+    assert np.isclose(pre.achieved_ratio, float(g["ratio"]), rtol=1e-4)
+    w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-6, 500, pre, False)
+    assert niter == int(g["niter"]) and niter < 10
+    assert rel(w, g["weights"]) < 1e-5
+    z = kern.transform_x(g["xtest"])
+    preds = (z @ w).cpu().numpy() * ds.get_ystd() + ds.get_ymean()
+    assert np.allclose(preds, g["preds"], rtol=1e-5, atol=1e-6)
+
+
+def test_conv_kernel_cg_matches_oracle(oracle):
+    """Conv1d kernel through the un-fused chunk path (Z materialised per chunk) vs the oracle."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import cg_fit_lib_internal
+    rng = np.random.default_rng(5)
+    n, L, C = 300, 24, 8
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(5, L + 1, size=n).astype(np.int32)
+    y = rng.standard_normal(n)
+    hp = np.array([0.5, 0.7])
+    ds = build_regression_dataset(x, y, sl, chunk_size=128, device=DEV)
+    kern = make_kernel("Conv1dRBF", x.shape, 256, 123, DEV, {"conv_width": 5, "averaging": "sqrt"})
+    kern.set_hyperparams(hp, logspace=False)
+    w, niter, _ = cg_fit_lib_internal(kern, ds, 1e-9, 300, None, False)
+    ods = orc.OracleDataset(x.astype(np.float64), y, sl, chunk_size=128)
+    okern = orc.OracleKernel("Conv1dRBF", 256, x.shape, hp, 123, conv_width=5, averaging="sqrt", ops=oracle)
+    wref, nref, _, _ = orc.cg_fit_lib_internal(okern, ods, 1e-9, 300, None)
+    assert abs(niter - nref) <= 1
+    assert rel(w, wref) < 1e-5

@@ -1,0 +1,79 @@
+"""CPU-only tests of the host-side mirror of the reference's kernel objects: the random
+draws (made on the host with the reference's numpy / scipy calls) must be bit-exact against
+the draws the reference's own kernel classes made (tests/golden/g6_draws.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_kernel_draws_bit_exact():
+    from xgpr_amd.kernels import make_kernel, SRHTCompressor
+    g = load_golden("g6_draws.npz")
+    cases = [("cfg1_RBF", "RBF", (1, 32), 512, {}), ("cfg2_RBF", "RBF", (1, 256), 4096, {}),
+             ("cfg3_Matern", "Matern", (1, 1024), 8192, {"matern_nu": 5 / 2}),
+             ("cfg3_Cauchy", "Cauchy", (1, 1024), 8192, {}), ("cfg5_RBF", "RBF", (1, 512), 32768, {}),
+             ("fix_RBF", "RBF", (1, 84), 4096, {}), ("small_RBF", "RBF", (1, 3), 64, {}),
+             ("cfg4_Conv1dRBF", "Conv1dRBF", (1, 512, 21), 16384, {"conv_width": 9}),
+             ("graph_GraphRBF", "GraphRBF", (1, 30, 12), 1024, {}),
+             ("conv_Conv1dMatern", "Conv1dMatern", (1, 60, 21), 2048, {"conv_width": 5, "matern_nu": 3 / 2})]
+    for tag, name, xdim, rffs, parms in cases:
+        k = make_kernel(name, xdim, rffs, random_seed=123, device="cpu", kernel_spec_parms=parms)
+        assert k.radem_diag.dtype == torch.int8 and k.chi_arr.dtype == torch.float32
+        assert np.array_equal(k.radem_diag.numpy(), g[f"{tag}_radem"]), tag
+        assert np.array_equal(k.chi_arr.numpy(), g[f"{tag}_chi"]), tag
+    for tag, rank, m in [("srht_256_4096", 256, 4096), ("srht_512_8192", 512, 8192),
+                         ("srht_64_512", 64, 512), ("srht_100_1000", 100, 1000)]:
+        c = SRHTCompressor(rank, m, device="cpu", random_seed=123)
+        assert np.array_equal(c.radem.numpy(), g[f"{tag}_radem"])
+        assert np.array_equal(c.col_sampler.numpy(), g[f"{tag}_col_sampler"])
+
+
+def test_draw_anchors_from_survey():
+    """Anchors recorded in SURVEY.md section 8c (seed 123)."""
+    import hashlib
+    from xgpr_amd.kernels import make_kernel
+    k = make_kernel("Matern", (1, 1024), 8192, device="cpu", kernel_spec_parms={"matern_nu": 2.5})
+    assert hashlib.sha256(k.radem_diag.numpy().tobytes()).hexdigest()[:16] == "de51cbb1014e6be3"
+    assert np.allclose(k.chi_arr[:3].numpy(), [49.065594, 23.925774, 25.538355], rtol=1e-7)
+    k = make_kernel("RBF", (1, 32), 512, device="cpu")
+    assert hashlib.sha256(k.radem_diag.numpy().tobytes()).hexdigest()[:16] == "61db7b68b904dece"
+    assert k.radem_diag.numpy().ravel()[:8].tolist() == [-1, 1, 1, -1, 1, -1, -1, -1]
+
+
+def test_kernel_argument_errors():
+    from xgpr_amd.kernels import make_kernel
+    with pytest.raises(RuntimeError):
+        make_kernel("RBF", (1, 10), 31, device="cpu")
+    with pytest.raises(ValueError):
+        make_kernel("RBF", (1, 10, 3), 32, device="cpu")
+    with pytest.raises(ValueError):
+        make_kernel("Matern", (1, 10), 32, device="cpu")
+    with pytest.raises(ValueError):
+        make_kernel("Conv1dRBF", (1, 10, 3), 32, device="cpu")
+    with pytest.raises(RuntimeError):
+        make_kernel("Linear", (1, 10), 32, device="cpu")
+
+
+def test_scale_input_matches_numpy_inplace():
+    """``input_x *= hyperparams[1]`` on a float32 array with an np.float64 scalar (numpy 2)."""
+    from xgpr_amd.kernels import scale_input
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((50, 7)).astype(np.float32)
+    hp = np.array([0.3, 0.358])
+    ref = x.copy()
+    ref *= hp[1]
+    got = scale_input(torch.from_numpy(x), hp[1]).numpy()
+    assert np.array_equal(got, ref)
+
+
+def test_shard_bounds_cover_rows():
+    from xgpr_amd.dist import Comm
+    for n in [1, 7, 8, 1000003]:
+        for ws in [1, 2, 3, 8]:
+            spans = [Comm(r, ws).shard_bounds(n) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -36,6 +36,7 @@ SIGNATURES = {
 }
 SIZE_FUNCS = {
     "xgpr_rbf_workspace_bytes": [_l],
+    "xgpr_sorf_workspace_bytes": [_l, _l, _i],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
 }
 STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch"]
@@ -51,7 +52,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
-            "(run `python -m xgpr_amd.build`); xgpr_amd has no CPU fallback.")
+            "(run `python xgpr_amd/build.py`); xgpr_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -1,6 +1,6 @@
 """Builds libxgpr_hip.so (the C-ABI library with the gfx950 kernels) in-tree with hipcc.
 
-    python -m xgpr_amd.build [--force]
+    python xgpr_amd/build.py [--force]      (run as a script: importing the package needs the built library)
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the authoring container;
 the built .so travels to the GPU box with the repository snapshot.

@@ -1,0 +1,162 @@
+"""Preconditioned conjugate gradients on the device, mirroring the reference solver.
+
+  * ``ConjugateGrad._matvec`` / ``.fit``  <-> CPU/GPU_ConjugateGrad (fitting_toolkit/cg_tools.py:173-302 / :26-156)
+  * ``cg_fit_lib_internal``               <-> fitting_toolkit/cg_fitting_toolkit.py:18-70
+  * ``calc_zty``                          <-> scoring_toolkit/exact_nmll_calcs.py:13-39
+
+What differs from the reference, on purpose: the matvec never materialises Z when the kernel
+has a fused HIP path (``kernel.ztz_matvec``: feature generation + Z^T(Zv) in one launch over
+the whole HBM-resident shard), and the per-rank partial ``w`` is summed over ranks with one
+RCCL all-reduce per iteration before ``lambda^2 v`` is added -- all ranks then run identical
+float64 vector updates, so alpha / beta / err agree everywhere with no further communication.
+Kept from the reference: float64 CG state, the two-column ping-pong buffers, solving for
+``zty / N`` and rescaling, and the lagging ``err`` (computed from the current column after the
+next one was written, cg_tools.py:265), so iteration counts match.
+"""
+import warnings
+
+import torch
+
+from .dist import SINGLE
+
+
+def calc_zty(dataset, kernel):
+    """exact_nmll_calcs.py:13-39 -> (z^T y [M] f64 device, y^T y float), summed over ranks."""
+    comm = dataset.comm
+    m = kernel.get_num_rffs()
+    z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
+    if kernel.fused_ok():
+        y = dataset.normalized_y()
+        kernel.zty(dataset.scaled_x(kernel.hyperparams[1]), y, z_trans_y)
+        y_trans_y = (y ** 2).sum().reshape(1)
+    else:
+        y_trans_y = torch.zeros(1, dtype=torch.float64, device=kernel.device)
+        for xin, yin, ldata in dataset.get_chunked_data():
+            zdata, ydata = kernel.transform_x_y(xin, yin, ldata)
+            z_trans_y += zdata.T @ ydata
+            y_trans_y += (ydata ** 2).sum()
+    comm.all_reduce_(z_trans_y)
+    comm.all_reduce_(y_trans_y)
+    return z_trans_y, float(y_trans_y.item())
+
+
+class ConjugateGrad:
+    """Batched-RHS preconditioned CG for (Z^T Z + lambda^2) b = rhs."""
+
+    def __init__(self, comm=SINGLE):
+        self.comm = comm
+        self._ws = None
+
+    def _matvec(self, dataset, kernel, vec, matvec):
+        """cg_tools.py:173-200 (regression branch): matvec <- (Z^T Z + lambda^2) vec."""
+        matvec.zero_()
+        if kernel.fused_ok():
+            xs = dataset.scaled_x(kernel.hyperparams[1])
+            if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != xs.device:
+                self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=xs.device)
+            if vec.shape[1] == 1:
+                kernel.ztz_matvec(xs, vec[:, 0].contiguous(), matvec[:, 0], self._ws) \
+                    if matvec[:, 0].is_contiguous() else self._matvec_cols(kernel, xs, vec, matvec)
+            else:
+                self._matvec_cols(kernel, xs, vec, matvec)
+        else:
+            for x, lengths in dataset.get_chunked_x_data():
+                z = kernel.transform_x(x, lengths)
+                matvec += z.T @ (z @ vec)
+        self.comm.all_reduce_(matvec)
+        matvec += kernel.get_lambda() ** 2 * vec
+
+    def _matvec_cols(self, kernel, xs, vec, matvec):
+        tmp = torch.empty(vec.shape[0], dtype=torch.float64, device=vec.device)
+        for j in range(vec.shape[1]):
+            kernel.ztz_matvec(xs, vec[:, j].contiguous(), tmp, self._ws)
+            matvec[:, j] = tmp
+
+    def fit(self, dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, verbose=True,
+            nmll_settings=False, trace=None):
+        """cg_tools.py:203-302.  ``resid`` is [M, 2, k] float64 with column 0 holding the
+        right-hand side; starting weights are zero.  Returns (x_k, converged, niter, losses),
+        or (x_k, alphas, betas) with ``nmll_settings``."""
+        dev = resid.device
+        converged = False
+        target = resid[:, 0, :].clone()
+        init_norms = torch.linalg.norm(target, dim=0)
+        m, k = resid.shape[0], resid.shape[2]
+        z_k = torch.zeros((m, 2, k), dtype=torch.float64, device=dev)
+        p_k = torch.zeros((m, 2, k), dtype=torch.float64, device=dev)
+        alphas, betas, losses = [], [], []
+        x_k = torch.zeros((m, k), dtype=torch.float64, device=dev)
+        w = torch.zeros((m, k), dtype=torch.float64, device=dev)
+
+        if preconditioner is None:
+            z_k[:, 0, :] = resid[:, 0, :]
+        else:
+            z_k[:, 0, :] = preconditioner.batch_matvec(resid[:, 0, :])
+        p_k[:, 0, :] = z_k[:, 0, :]
+
+        next_col, current_col = 1, 0
+        niter = 0
+        for niter in range(maxiter):
+            p_cur = p_k[:, current_col, :].contiguous()
+            self._matvec(dataset, kernel, p_cur, w)
+            r_cur, z_cur = resid[:, current_col, :], z_k[:, current_col, :]
+            rz = (r_cur * z_cur).sum(dim=0)
+            alpha = rz / (p_cur * w).sum(dim=0)
+            x_k += alpha[None, :] * p_cur
+            resid[:, next_col, :] = r_cur - alpha[None, :] * w
+            err = torch.linalg.norm(r_cur, dim=0) / init_norms
+            r_next = resid[:, next_col, :]
+            if preconditioner is None:
+                z_k[:, next_col, :] = r_next
+            else:
+                z_k[:, next_col, :] = preconditioner.batch_matvec(r_next)
+            beta = (r_next * z_k[:, next_col, :]).sum(dim=0) / rz
+            p_k[:, next_col, :] = z_k[:, next_col, :] + beta[None, :] * p_cur
+
+            err_host = err.cpu()          # the one host sync of the iteration
+            if nmll_settings:
+                alphas.append(alpha.clone())
+                betas.append(beta.clone())
+            else:
+                losses.append(float(err_host[0]))
+            if trace is not None:
+                trace.setdefault("x_k", []).append(x_k.clone())
+                trace.setdefault("alpha", []).append(alpha.clone())
+                trace.setdefault("beta", []).append(beta.clone())
+
+            next_col, current_col = abs(next_col - 1), abs(current_col - 1)
+            if niter % 5 == 0 and verbose and self.comm.rank == 0:
+                print(f"{niter} iterations complete.")
+            if float(err_host.max()) < tol:
+                converged = True
+                break
+
+        if nmll_settings:
+            alphas, betas = torch.stack(alphas), torch.stack(betas)
+            return x_k, alphas[:, 1:], betas[:, 1:]
+        if x_k.shape[1] > 1:
+            return x_k, converged, niter + 1, losses
+        return x_k[:, 0], converged, niter + 1, losses
+
+
+def cg_fit_lib_internal(kernel, dataset, cg_tol=1e-4, max_iter=500, preconditioner=None,
+                        verbose=True, trace=None):
+    """cg_fitting_toolkit.py:18-70 -> (weights [M] f64 device, n_iter, losses)."""
+    comm = dataset.comm
+    cg_operator = ConjugateGrad(comm)
+    resid = torch.zeros((kernel.get_num_rffs(), 2, 1), dtype=torch.float64, device=kernel.device)
+    if preconditioner is None:
+        z_trans_y, _ = calc_zty(dataset, kernel)
+    else:
+        z_trans_y = preconditioner.get_zty()
+    resid[:, 0, :] = z_trans_y[:, None] / dataset.get_ndatapoints()
+    weights, converged, n_iter, losses = cg_operator.fit(dataset, kernel, preconditioner, resid,
+                                                         max_iter, cg_tol, verbose,
+                                                         nmll_settings=False, trace=trace)
+    weights *= dataset.get_ndatapoints()
+    if not converged:
+        warnings.warn("Conjugate gradients failed to converge! Try refitting "
+                      "the model with updated settings.")
+    if verbose and comm.rank == 0:
+        print(f"CG iterations: {n_iter}")
+    return weights, n_iter, losses

@@ -74,6 +74,8 @@ int device_cus() {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // ------------------------------------------------------------------------------------
 // device math
 // ------------------------------------------------------------------------------------
@@ -214,20 +216,24 @@ template <typename T> struct SorfArgs {
     int kmer_stride;  // C for the conv ops
     int conv_width; int P; int reps; int scaling_type;
     T nc; double scale; double sigma;
+    T *scratch;       // GLOBALBUF only: one P-element buffer per workgroup, in global memory
 };
 
 // one workgroup per (datapoint i = blockIdx.x, repeat k = blockIdx.y); for the conv ops the
 // k-mer loop runs inside the workgroup in the reference's order (j ascending), each thread
 // owning its output elements, so the f64 accumulation order equals the reference's.
-template <typename T, int MODE>
+template <typename T, int MODE, bool GLOBALBUF>
 __global__ void generic_sorf_kernel(SorfArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *buf = reinterpret_cast<T *>(smem);
+    // widths beyond the LDS capacity (P > 32768 float / 16384 double) run the same code on a
+    // per-workgroup buffer in global memory (__syncthreads orders it at workgroup scope)
+    T *buf = GLOBALBUF ? a.scratch + (long)blockIdx.x * a.P : reinterpret_cast<T *>(smem);
     const int tid = threadIdx.x, nt = blockDim.x;
-    const long i = blockIdx.x;
-    const int k = blockIdx.y;
     const int P = a.P;
     constexpr bool CONVLIKE = (MODE == MODE_CONV || MODE == MODE_CONV_GRAD || MODE == MODE_MAXPOOL);
+  for (long item = blockIdx.x; item < a.n * a.reps; item += gridDim.x) {
+    const long i = item / a.reps;
+    const int k = (int)(item % a.reps);
     int nk = 1;
     double rs = a.scale;
     if (CONVLIKE) {
@@ -292,6 +298,7 @@ __global__ void generic_sorf_kernel(SorfArgs<T> a) {
         }
         __syncthreads();
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -743,17 +750,32 @@ int launch_fht(T *x, const int8_t *radem, long nvec, long P, hipStream_t st) {
     return 0;
 }
 
+constexpr long GENERIC_SCRATCH_SLOTS = 256;
+
+// bytes of global scratch the generic path needs for padded width P (0 when it fits in LDS)
+size_t generic_scratch_bytes(long P, size_t elem) {
+    return (size_t)P * elem > (size_t)LDS_CAP_BYTES ? (size_t)GENERIC_SCRATCH_SLOTS * P * elem : 0;
+}
+
 template <typename T, int MODE>
-int launch_generic_sorf(const SorfArgs<T> &a, hipStream_t st) {
-    if ((long)a.P > lds_cap_elems<T>())
-        return fail(XGPR_ERR_UNSUPPORTED, "padded width exceeds the LDS-resident limit (32768 float / 16384 double)");
+int launch_generic_sorf(SorfArgs<T> a, void *workspace, size_t wbytes, hipStream_t st) {
+    long items = a.n * a.reps;
+    if ((long)a.P > lds_cap_elems<T>()) {
+        const size_t need = generic_scratch_bytes(a.P, sizeof(T));
+        if (!workspace || wbytes < need || !aligned16(workspace))
+            return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_sorf_workspace_bytes)");
+        a.scratch = reinterpret_cast<T *>(workspace);
+        const long nblocks = items < GENERIC_SCRATCH_SLOTS ? items : GENERIC_SCRATCH_SLOTS;
+        hipLaunchKernelGGL((generic_sorf_kernel<T, MODE, true>), dim3((unsigned)nblocks), dim3(1024), 0, st, a);
+        HIP_TRY(hipGetLastError(), "generic_sorf_kernel launch");
+        return 0;
+    }
     const size_t lds = (size_t)a.P * sizeof(T);
-    auto kern = generic_sorf_kernel<T, MODE>;
+    auto kern = generic_sorf_kernel<T, MODE, false>;
     int rc = allow_big_lds(kern, lds);
     if (rc) return rc;
-    if (a.n > 2147483647L || a.reps > 65535)
-        return fail(XGPR_ERR_UNSUPPORTED, "grid too large for the generic path");
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.n, (unsigned)a.reps), dim3(threads_for(a.P)), lds, st, a);
+    const long nblocks = items < (1L << 20) ? items : (1L << 20);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(threads_for(a.P)), lds, st, a);
     HIP_TRY(hipGetLastError(), "generic_sorf_kernel launch");
     return 0;
 }
@@ -782,8 +804,6 @@ void fill_norms(WaveArgs &a, int lg) {
     if (lg & 1) { a.nc = nc; a.chi_scale = 1.0f; }
     else { a.nc = 1.0f; a.chi_scale = nc * nc * nc; }   // exact power of two
 }
-
-bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ------------------------------------------------------------------------------------
 // validation shared by the entry points (mirrors the reference's throw sites)
@@ -872,10 +892,10 @@ int rbf_impl(const T *x, double *out, double *grad, const int8_t *radem, const T
     if (want_grad) {
         // rbf_ops.cpp:180-185: a double constant in the gradient op
         a.scale = fit_intercept ? sqrt(1.0 / ((double)num_freqs - 0.5)) : sqrt(1.0 / (double)num_freqs);
-        return launch_generic_sorf<T, MODE_RBF_GRAD>(a, st);
+        return launch_generic_sorf<T, MODE_RBF_GRAD>(a, workspace, wbytes, st);
     }
     a.scale = rbf_scale<T>(num_freqs, fit_intercept);
-    return launch_generic_sorf<T, MODE_RBF>(a, st);
+    return launch_generic_sorf<T, MODE_RBF>(a, workspace, wbytes, st);
 }
 
 template <typename T>
@@ -938,9 +958,9 @@ int conv_impl(const T *x, double *out, double *grad, float *outf, const int8_t *
     a.n = n; a.row_stride = L * C; a.F = num_freqs; a.R = R; a.d = (int)win; a.kmer_stride = (int)C;
     a.conv_width = conv_width; a.P = (int)P; a.reps = reps; a.scaling_type = scaling_type;
     a.nc = norm_constant<T>(P); a.scale = sqrt(1.0 / (double)num_freqs); a.sigma = sigma;
-    if (mode == MODE_CONV) return launch_generic_sorf<T, MODE_CONV>(a, st);
-    if (mode == MODE_CONV_GRAD) return launch_generic_sorf<T, MODE_CONV_GRAD>(a, st);
-    return launch_generic_sorf<T, MODE_MAXPOOL>(a, st);
+    if (mode == MODE_CONV) return launch_generic_sorf<T, MODE_CONV>(a, workspace, wbytes, st);
+    if (mode == MODE_CONV_GRAD) return launch_generic_sorf<T, MODE_CONV_GRAD>(a, workspace, wbytes, st);
+    return launch_generic_sorf<T, MODE_MAXPOOL>(a, workspace, wbytes, st);
 }
 
 constexpr long ZTZ_MAX_SLABS = 1024;
@@ -1014,6 +1034,11 @@ int xgpr_srht_f64(double *x, const int8_t *radem, long n, long dim, long radem_l
 }
 
 size_t xgpr_rbf_workspace_bytes(long radem_shape2) { return masks_bytes(radem_shape2); }
+size_t xgpr_sorf_workspace_bytes(long radem_shape2, long width, int elem_size) {
+    const size_t a = masks_bytes(radem_shape2);
+    const size_t b = generic_scratch_bytes(padded_width(width), (size_t)elem_size);
+    return a > b ? a : b;
+}
 
 int xgpr_rbf_feature_gen_f32(const float *x, double *out, const int8_t *radem, const float *chi, long n, long d,
                              long out_rows, long num_rffs, long num_freqs, long radem_shape2, int fit_intercept,

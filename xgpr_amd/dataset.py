@@ -1,0 +1,115 @@
+"""Device-resident, row-sharded counterpart of the reference's OnlineDataset.
+
+Mirrors data_handling/online_data_handling.py:54-94 (chunk generators; y standardised with
+the stored training mean / std, :66-68) and data_handling/dataset_builder.py:14-178
+(``build_regression_dataset``: trainy_mean = y.mean(), trainy_std = y.std()).  Differences,
+both deliberate: the shard lives in HBM as float32 (the reference re-casts and re-uploads
+every chunk on every CG iteration, kernels/kernel_baseclass.py:274-288), and with more than
+one rank every rank holds a contiguous row range while the y statistics and
+``get_ndatapoints()`` are global.
+"""
+import numpy as np
+import torch
+
+from .dist import SINGLE
+
+
+class DeviceDataset:
+    def __init__(self, xdata, ydata, sequence_lengths=None, chunk_size=2000,
+                 trainy_mean=0.0, trainy_std=1.0, ndatapoints=None, device="cuda", comm=SINGLE):
+        self.device = device
+        self.comm = comm
+        self._xdata = xdata
+        self._ydata = ydata          # float64, raw (un-normalised), on the device
+        self._sequence_lengths = sequence_lengths   # host int32 numpy array or None
+        self._chunk_size = int(chunk_size)
+        self._trainy_mean, self._trainy_std = float(trainy_mean), float(trainy_std)
+        self._ndatapoints = int(ndatapoints if ndatapoints is not None else xdata.shape[0])
+        self._scaled = {}
+
+    # ---- the reference's accessors (data_handling_baseclass.py)
+    def get_ndatapoints(self):
+        return self._ndatapoints
+
+    def get_local_ndatapoints(self):
+        return self._xdata.shape[0]
+
+    def get_chunk_size(self):
+        return self._chunk_size
+
+    def get_xdim(self):
+        return (self._ndatapoints,) + tuple(self._xdata.shape[1:])
+
+    def get_ymean(self):
+        return self._trainy_mean
+
+    def get_ystd(self):
+        return self._trainy_std
+
+    def normalized_y(self):
+        """(y - mean) / std as float64, the chunk-wise transform of
+        online_data_handling.py:66-68 applied to the whole shard."""
+        y = self._ydata.to(torch.float64).clone()
+        y -= self._trainy_mean
+        y /= self._trainy_std
+        return y
+
+    def get_chunked_data(self):
+        n = self._xdata.shape[0]
+        for i in range(0, n, self._chunk_size):
+            j = min(i + self._chunk_size, n)
+            ychunk = self._ydata[i:j].to(torch.float64).clone()
+            ychunk -= self._trainy_mean
+            ychunk /= self._trainy_std
+            lchunk = None if self._sequence_lengths is None else self._sequence_lengths[i:j]
+            yield self._xdata[i:j, ...], ychunk, lchunk
+
+    def get_chunked_x_data(self):
+        n = self._xdata.shape[0]
+        for i in range(0, n, self._chunk_size):
+            j = min(i + self._chunk_size, n)
+            lchunk = None if self._sequence_lengths is None else self._sequence_lengths[i:j]
+            yield self._xdata[i:j, ...], lchunk
+
+    def scaled_x(self, sigma):
+        """The whole shard pre-multiplied by sigma (what ``transform_x`` does to each chunk
+        copy, sorf_kernel_baseclass.py:117), cached per sigma for the fused kernels."""
+        from .kernels import scale_input
+        key = float(sigma)
+        if key not in self._scaled:
+            self._scaled = {key: scale_input(self._xdata, key)}
+        return self._scaled[key]
+
+
+def build_regression_dataset(xdata, ydata, sequence_lengths=None, chunk_size=2000, device="cuda",
+                             comm=SINGLE, already_sharded=False):
+    """dataset_builder.py:14-178 for in-memory arrays.  ``xdata`` / ``ydata`` are numpy arrays
+    or tensors; with ``comm.world_size > 1`` each rank keeps rows ``comm.shard_bounds(N)`` unless
+    ``already_sharded`` (then the arrays passed are this rank's rows)."""
+    xt = torch.from_numpy(np.ascontiguousarray(xdata)) if isinstance(xdata, np.ndarray) else xdata
+    yt = torch.from_numpy(np.ascontiguousarray(ydata)) if isinstance(ydata, np.ndarray) else ydata
+    if xt.shape[0] != yt.shape[0]:
+        raise RuntimeError("Different number of datapoints in x and y.")
+    sl = sequence_lengths
+    if sl is not None:
+        if xt.dim() != 3:
+            raise RuntimeError("sequence_lengths supplied for a 2d array.")
+        sl = np.ascontiguousarray(np.asarray(sl).astype(np.int32))
+        if sl.max() > xt.shape[1] or sl.min() < 1:
+            raise RuntimeError("sequence lengths out of range.")
+    if comm.world_size > 1 and not already_sharded:
+        lo, hi = comm.shard_bounds(xt.shape[0])
+        xt, yt = xt[lo:hi], yt[lo:hi]
+        if sl is not None:
+            sl = sl[lo:hi]
+    xt = xt.to(device=device, dtype=torch.float32).contiguous()
+    yt = yt.to(device=device, dtype=torch.float64).contiguous()
+    # global mean / population std (numpy's .std()), two passes in float64
+    stats = torch.stack([yt.sum(), torch.tensor(float(yt.shape[0]), dtype=torch.float64, device=device)])
+    comm.all_reduce_(stats)
+    n_global = int(round(stats[1].item()))
+    mean = stats[0] / stats[1]
+    ssq = ((yt - mean) ** 2).sum().reshape(1)
+    comm.all_reduce_(ssq)
+    std = torch.sqrt(ssq[0] / stats[1])
+    return DeviceDataset(xt, yt, sl, chunk_size, mean.item(), std.item(), n_global, device, comm)

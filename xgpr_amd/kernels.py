@@ -1,0 +1,253 @@
+"""Host-side counterparts of the reference's kernel objects for the hot path.
+
+Mirrors (paths relative to /root/reference/src/xGPR/kernels/):
+  * ``KernelBaseclass`` transform_x / transform_x_y          kernel_baseclass.py:269-324
+  * ``SORFKernelBaseclass`` (RBF, Matern, Cauchy)             basic_kernels/sorf_kernel_baseclass.py:36-126,
+                                                              matern.py:26-58, cauchy.py:21-45
+  * ``ConvKernelBaseclass`` (Conv1d*/Graph* RBF/Matern/Cauchy) convolution_kernels/conv_kernel_baseclass.py:41-147
+  * ``SRHTCompressor``                                        srht_compressor.py:37-97
+
+The random draws (Rademacher diagonals, chi / chi-square / exponential samples, the SRHT
+column permutation) are made on the host with exactly the numpy / scipy calls the reference
+makes -- they are *inputs* of the GPU path and must be bit-identical (tests/golden/g6_draws.npz).
+Everything that touches datapoints runs in libxgpr_hip.so on the device.
+"""
+from math import ceil
+
+import numpy as np
+import torch
+from scipy.stats import chi as _chi
+
+from . import xgpr_hip_rfgen_ext as ext
+
+
+def padded_dims(width):
+    return 2 ** ceil(np.log2(max(width, 2)))
+
+
+def scale_input(x, sigma, out_dtype=torch.float32):
+    """``input_x *= self.hyperparams[1]`` (sorf_kernel_baseclass.py:117) on a private copy.
+    hyperparams[1] is an np.float64 *scalar*: under numpy >= 2 (NEP 50, the version the golden
+    vectors were produced with) the product is formed in float64 and rounded back to the
+    array's dtype."""
+    return (x.to(torch.float64) * float(sigma)).to(out_dtype).contiguous()
+
+
+class KernelBase:
+    """State shared by all hot-path kernels (kernel_baseclass.py:49-99)."""
+
+    def __init__(self, num_rffs, xdim, kernel_spec_parms=None, device="cuda"):
+        kernel_spec_parms = kernel_spec_parms or {}
+        if num_rffs < 2:
+            raise RuntimeError("num_rffs should always be >= 2.")
+        if not (num_rffs / 2).is_integer():
+            raise RuntimeError("For sine-cosine kernels (e.g. matern, rbf) the number of random "
+                               "fourier features must be an integer multiple of two.")
+        self.num_freqs = int(num_rffs / 2)
+        self.num_rffs = int(num_rffs)
+        self.fit_intercept = kernel_spec_parms.get("intercept", True) is not False
+        self._xdim = tuple(xdim)
+        self.hyperparams = np.ones((2))
+        self.device = device
+        self.double_precision = False
+
+    # ---- hyperparameters (kernel_baseclass.py:219-266)
+    def get_hyperparams(self, logspace=True):
+        return np.log(self.hyperparams) if logspace else self.hyperparams
+
+    def set_hyperparams(self, hyperparams, logspace=True):
+        self.hyperparams = np.exp(hyperparams) if logspace else np.asarray(hyperparams, dtype=np.float64)
+
+    def get_lambda(self):
+        return self.hyperparams[0]
+
+    def get_num_rffs(self):
+        return self.num_rffs
+
+    def _to_device(self, radem, chi_arr):
+        self.radem_diag = torch.from_numpy(np.ascontiguousarray(radem)).to(self.device)
+        self.chi_arr = torch.from_numpy(np.ascontiguousarray(chi_arr)).to(self.device)
+
+    def _as_device_f32(self, input_x):
+        if isinstance(input_x, np.ndarray):
+            input_x = torch.from_numpy(np.ascontiguousarray(input_x))
+        return input_x.to(self.device)
+
+    def transform_x(self, input_x, sequence_length=None):
+        """kernel_baseclass.py:269-299: private float32 copy -> kernel_specific_transform ->
+        ``xtrans[:, 0] = 1`` when fitting an intercept.  Returns a float64 device tensor."""
+        xin = scale_input(self._as_device_f32(input_x), self.hyperparams[1])
+        xtrans = self.kernel_specific_transform(xin, sequence_length)
+        if self.fit_intercept:
+            xtrans[:, 0] = 1.
+        return xtrans
+
+    def transform_x_y(self, input_x, input_y, sequence_length=None):
+        """kernel_baseclass.py:303-324 (regression branch)."""
+        xtrans = self.transform_x(input_x, sequence_length)
+        if isinstance(input_y, np.ndarray):
+            input_y = torch.from_numpy(input_y)
+        return xtrans, input_y.to(self.device, torch.float64)
+
+
+class SORFKernel(KernelBase):
+    """RBF / Matern / Cauchy on fixed-length vectors."""
+
+    def __init__(self, kernel_choice, xdim, num_rffs, random_seed=123, device="cuda",
+                 kernel_spec_parms=None):
+        kernel_spec_parms = kernel_spec_parms or {}
+        super().__init__(num_rffs, xdim, kernel_spec_parms, device)
+        if len(xdim) != 2:
+            raise ValueError("The dimensionality of the input is inappropriate for "
+                             "the kernel you have selected.")
+        self.kernel_choice = kernel_choice
+        pdims = padded_dims(xdim[-1])
+        radem_array = np.asarray([-1, 1], dtype=np.int8)
+        rng = np.random.default_rng(random_seed)
+        nblocks = ceil(self.num_freqs / pdims) if pdims < self.num_freqs else 1
+        radem = rng.choice(radem_array, size=(3, 1, nblocks * pdims), replace=True)
+        chi_arr = _chi.rvs(df=pdims, size=self.num_freqs, random_state=random_seed).astype(np.float32)
+        chi_arr = _rescale_chi(kernel_choice, chi_arr, random_seed, kernel_spec_parms, self)
+        self._to_device(radem, chi_arr)
+
+    def kernel_specific_transform(self, input_x, sequence_length=None):
+        """sorf_kernel_baseclass.py:104-126; ``input_x`` is already sigma-scaled here."""
+        output_x = torch.empty((input_x.shape[0], self.num_rffs), dtype=torch.float64, device=self.device)
+        ext.hipRBFFeatureGen(input_x, output_x, self.radem_diag, self.chi_arr, self.fit_intercept)
+        return output_x
+
+    # ---- fused per-shard reductions (what the reference does chunk by chunk with a
+    # materialised Z: fitting_toolkit/cg_tools.py:189-191, scoring_toolkit/exact_nmll_calcs.py:35-37)
+    supports_fused = True
+
+    def ztz_matvec(self, x_scaled, vec, out, workspace=None):
+        ext.hipZtZMatvec(x_scaled, self.radem_diag, self.chi_arr, vec, out, self.fit_intercept, workspace)
+
+    def zty(self, x_scaled, y, out, workspace=None):
+        ext.hipZtY(x_scaled, self.radem_diag, self.chi_arr, y, out, self.fit_intercept, workspace)
+
+    def fused_ok(self):
+        """The fused kernels cover padded width <= 1024 and num_freqs <= 8192."""
+        return padded_dims(self._xdim[-1]) <= 1024 and self.num_freqs <= 8192
+
+    def workspace_bytes(self):
+        return ext.ztz_workspace_bytes(self.num_rffs, self.radem_diag.shape[2])
+
+
+def _rescale_chi(kernel_choice, chi_arr, random_seed, parms, obj):
+    """Matern: matern.py:45-54 (conv twins conv1d_matern.py:58-62, graph_matern.py:51-55);
+    Cauchy: cauchy.py:39-41 (conv1d_cauchy.py:52-54, graph_cauchy.py:45-47).  The rescale is
+    applied in place to the float32 array, as in the reference."""
+    if kernel_choice.endswith("Matern"):
+        if "matern_nu" not in parms:
+            raise ValueError("Tried to initialize a Matern kernel without supplying nu.")
+        obj.matern_nu = parms["matern_nu"]
+        if obj.matern_nu < 1 / 2 or obj.matern_nu > 5 / 2:
+            raise ValueError("nu must be >= 1/2 and <= 5/2.")
+        rng = np.random.default_rng(random_seed)
+        chisamples = np.sqrt(rng.chisquare(2 * obj.matern_nu, size=chi_arr.shape[0]) / (obj.matern_nu * 2))
+        chi_arr /= chisamples
+    elif kernel_choice.endswith("Cauchy"):
+        rng = np.random.default_rng(random_seed)
+        dstsamples = np.sqrt(rng.exponential(size=chi_arr.shape[0]))
+        chi_arr *= dstsamples
+    return chi_arr
+
+
+class ConvSORFKernel(KernelBase):
+    """Conv1dRBF / Conv1dMatern / Conv1dCauchy and the Graph* kernels (conv_width = 1,
+    graph_rbf.py:42-43)."""
+
+    def __init__(self, kernel_choice, xdim, num_rffs, random_seed=123, device="cuda",
+                 kernel_spec_parms=None):
+        kernel_spec_parms = kernel_spec_parms or {}
+        super().__init__(num_rffs, xdim, kernel_spec_parms, device)
+        if len(xdim) != 3:
+            raise RuntimeError("Tried to initialize a Conv1d kernel with a 2d x-"
+                               "array! x should be a 3d array for Conv1d.")
+        self.kernel_choice = kernel_choice
+        if kernel_choice.startswith("Graph"):
+            self.conv_width = 1
+        else:
+            if "conv_width" not in kernel_spec_parms:
+                raise ValueError("conv_width must be included as a kernel-specific "
+                                 "parameter if using a sequence kernel.")
+            self.conv_width = kernel_spec_parms["conv_width"]
+        averaging = kernel_spec_parms.get("averaging", "none")
+        if averaging not in ("none", "sqrt", "full"):
+            raise RuntimeError("Unrecognized value for 'averaging' supplied, "
+                               "should be one of 'none', 'sqrt', 'full'.")
+        self.scaling_type = {"none": 0, "sqrt": 1, "full": 2}[averaging]
+        rng = np.random.default_rng(random_seed)
+        pdims = padded_dims(self.conv_width * xdim[2])
+        init_calc_freqsize = ceil(self.num_freqs / pdims) * pdims
+        radem_array = np.asarray([-1, 1], dtype=np.int8)
+        radem = rng.choice(radem_array, size=(3, 1, init_calc_freqsize), replace=True)
+        chi_arr = _chi.rvs(df=pdims, size=self.num_freqs, random_state=random_seed).astype(np.float32)
+        chi_arr = _rescale_chi(kernel_choice, chi_arr, random_seed, kernel_spec_parms, self)
+        self._to_device(radem, chi_arr)
+
+    supports_fused = False
+
+    def fused_ok(self):
+        return False
+
+    def kernel_specific_transform(self, input_x, sequence_length):
+        """conv_kernel_baseclass.py:116-147."""
+        if sequence_length is None:
+            raise RuntimeError("sequence_length is required for convolution kernels.")
+        if input_x.shape[2] != self._xdim[2]:
+            raise RuntimeError("Unexpected input shape supplied.")
+        if isinstance(sequence_length, torch.Tensor):
+            sequence_length = sequence_length.cpu().numpy()
+        slen = np.ascontiguousarray(sequence_length.astype(np.int32, copy=False))
+        xtrans = torch.zeros((input_x.shape[0], self.num_rffs), dtype=torch.float64, device=self.device)
+        ext.hipConv1dFGen(input_x, xtrans, self.radem_diag, self.chi_arr, slen,
+                          self.conv_width, self.scaling_type)
+        return xtrans
+
+
+_FIXED = ("RBF", "Matern", "Cauchy")
+_CONV = ("Conv1dRBF", "Conv1dMatern", "Conv1dCauchy", "GraphRBF", "GraphMatern", "GraphCauchy")
+
+
+def make_kernel(kernel_choice, xdim, num_rffs, random_seed=123, device="cuda", kernel_spec_parms=None):
+    """Counterpart of KERNEL_NAME_TO_CLASS (kernels/__init__.py:21-33) for the SORF kernels."""
+    if kernel_choice in _FIXED:
+        return SORFKernel(kernel_choice, xdim, num_rffs, random_seed, device, kernel_spec_parms)
+    if kernel_choice in _CONV:
+        return ConvSORFKernel(kernel_choice, xdim, num_rffs, random_seed, device, kernel_spec_parms)
+    raise RuntimeError(f"kernel '{kernel_choice}' is outside the hot path this package implements "
+                       f"(supported: {_FIXED + _CONV})")
+
+
+class SRHTCompressor:
+    """srht_compressor.py:37-97 -- double precision, as the preconditioner uses it."""
+
+    def __init__(self, compression_size, input_size, device="cuda", random_seed=123):
+        if compression_size >= input_size or compression_size <= 1:
+            raise RuntimeError("The compression size should be < the number of rffs and > 1.")
+        self.compression_size, self.input_size = compression_size, input_size
+        self.padded_dims = padded_dims(input_size)
+        radem_array = np.asarray([-1, 1], dtype=np.int8)
+        rng = np.random.default_rng(random_seed)
+        radem = rng.choice(radem_array, size=(self.padded_dims), replace=True)
+        col_sampler = rng.permutation(self.padded_dims)
+        self.device = device
+        self.radem = torch.from_numpy(radem).to(device)
+        self.col_sampler = torch.from_numpy(col_sampler).to(device)
+        self.truncated_sampler = self.col_sampler[:compression_size]
+
+    def transform_x(self, features, no_compression=False):
+        if features.dim() != 2 or features.shape[1] != self.input_size:
+            raise RuntimeError("Input with unexpected size passed to a compressor module.")
+        if features.shape[1] < self.padded_dims:
+            xfeatures = torch.zeros((features.shape[0], self.padded_dims), dtype=torch.float64,
+                                    device=self.device)
+            xfeatures[:, :features.shape[1]] = features
+        else:
+            xfeatures = features.to(torch.float64, copy=True).contiguous()
+        ext.hipSRHT(xfeatures, self.radem)
+        if no_compression:
+            return xfeatures[:, self.col_sampler]
+        return xfeatures[:, self.truncated_sampler]

@@ -1,0 +1,129 @@
+"""Randomized-Nystrom (SRHT) preconditioner on the device, mirroring the reference.
+
+  * ``RandNysPreconditioner``       <-> preconditioners/rand_nys_preconditioners.py:18-72
+  * ``single_pass_srht_zty``        <-> preconditioners/rand_nys_constructors.py:96-123
+  * ``single_pass_gauss``           <-> rand_nys_constructors.py:18-36
+  * ``initialize_srht``             <-> rand_nys_constructors.py:221-296
+  * ``initialize_srht_multipass``   <-> rand_nys_constructors.py:127-218
+
+The accumulation passes run per chunk on the device (SORF feature generation and the SRHT of
+the chunk are HIP kernels of libxgpr_hip.so; the dense ``[rank x n] @ [n x M]`` float64
+contractions are plain library GEMMs, rocBLAS through torch).  Per-rank partial sums
+(``acc``, ``Z^T y``, ``y^T y``) are combined with one RCCL all-reduce per pass; the small
+factorizations (SVD / QR / Cholesky of M x rank matrices) then run redundantly -- and
+identically -- on every rank (rocSOLVER through torch.linalg), which is cheaper than
+broadcasting U.
+"""
+import numpy as np
+import torch
+
+from .kernels import SRHTCompressor
+
+
+def single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose):
+    y_trans_y = torch.zeros(1, dtype=torch.float64, device=acc_results.device)
+    for j, (xin, yin, ldata) in enumerate(dataset.get_chunked_data()):
+        xdata, ydata = kernel.transform_x_y(xin, yin, ldata)
+        z_trans_y += xdata.T @ ydata
+        y_trans_y += ydata @ ydata
+        acc_results += compressor.transform_x(xdata).T @ xdata
+        if j % 10 == 0 and verbose:
+            print(f"Chunk {j} complete.")
+    return y_trans_y
+
+
+def single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose):
+    for j, (xdata, ldata) in enumerate(dataset.get_chunked_x_data()):
+        xdata = kernel.transform_x(xdata, ldata)
+        acc_results += xdata.T @ (xdata @ q_mat)
+        if j % 10 == 0 and verbose:
+            print(f"Chunk {j} complete.")
+
+
+def _first_pass(dataset, rank, kernel, random_state, verbose):
+    comm = dataset.comm
+    m = kernel.get_num_rffs()
+    acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
+    z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
+    compressor = SRHTCompressor(rank, m, device=kernel.device, random_seed=random_state)
+    y_trans_y = single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose)
+    comm.all_reduce_(acc_results)
+    comm.all_reduce_(z_trans_y)
+    comm.all_reduce_(y_trans_y)
+    return acc_results, z_trans_y, float(y_trans_y.item()), compressor
+
+
+def initialize_srht(dataset, rank, kernel, random_state, verbose=False):
+    acc_results, z_trans_y, y_trans_y, compressor = _first_pass(dataset, rank, kernel, random_state, verbose)
+    c_mat = compressor.transform_x(acc_results)
+    _, c_s1, c_v1 = torch.linalg.svd(c_mat, full_matrices=False)
+    mask = c_s1 < 1e-14
+    c_s1 = 1 / torch.sqrt(c_s1.clip(min=1e-14))
+    c_s1[mask] = 0
+    acc_results = acc_results.T @ c_v1.T @ (c_s1[:, None] * c_v1)
+    u_mat, s_mat, _ = torch.linalg.svd(acc_results, full_matrices=False)
+    s_mat = s_mat ** 2
+    return u_mat, s_mat, z_trans_y, y_trans_y
+
+
+def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False, n_passes=1):
+    comm = dataset.comm
+    acc_results, z_trans_y, y_trans_y, _ = _first_pass(dataset, rank, kernel, random_state, verbose)
+    acc_results = acc_results.T.contiguous()
+    q_mat = None
+    for _ in range(n_passes - 1):
+        q_mat, _r = torch.linalg.qr(acc_results)
+        acc_results.zero_()
+        single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose)
+        comm.all_reduce_(acc_results)
+    norm = float(torch.sqrt((acc_results ** 2).sum()).item())
+    shift = float(np.spacing(norm))
+    acc_results += shift * q_mat
+    q_mat = q_mat.T @ acc_results
+    q_mat = torch.linalg.cholesky(q_mat)
+    acc_results = torch.linalg.solve_triangular(q_mat, acc_results.T, upper=False).T
+    u_mat, s_mat, _ = torch.linalg.svd(acc_results, full_matrices=False)
+    s_mat = (s_mat ** 2 - shift).clip(min=0)
+    return u_mat, s_mat, z_trans_y, y_trans_y
+
+
+class RandNysPreconditioner:
+    """Preconditioner from the randomized Nystrom approximation of (Z^T Z + lambda^2)^-1."""
+
+    def __init__(self, kernel, dataset, max_rank, verbose=False, random_state=123, method="srht"):
+        if method not in ["srht_2", "srht_3", "srht"]:
+            raise RuntimeError("Unknown method supplied for tuning preconditioner construction.")
+        if method.startswith("srht_"):
+            n_passes = int(method.split("_")[1])
+            self.u_mat, self.eig, self.z_trans_y, self.y_trans_y = initialize_srht_multipass(
+                dataset, max_rank, kernel, random_state, verbose, n_passes)
+        else:
+            self.u_mat, self.eig, self.z_trans_y, self.y_trans_y = initialize_srht(
+                dataset, max_rank, kernel, random_state, verbose)
+        lambda_ = float(kernel.get_lambda())
+        min_eig = float(self.eig.min().item())
+        self.eig = self.eig + lambda_ ** 2
+        self.inv_eig = self.eig.clone()
+        mask = self.inv_eig > 1e-14
+        self.inv_eig[mask] = 1 / self.inv_eig[mask]
+        self.inv_eig[~mask] = 0.0
+        self.achieved_ratio = min_eig / lambda_ ** 2
+        self.prefactor = float(min_eig + lambda_ ** 2)
+        self.device = kernel.device
+        self.u_mat = self.u_mat.contiguous()
+
+    def batch_matvec(self, xvec):
+        """rand_nys_preconditioners.py:66-72."""
+        xprod = self.u_mat.T @ xvec
+        xprod1 = self.u_mat @ (self.inv_eig[:, None] * self.prefactor * xprod)
+        xprod2 = xvec - (self.u_mat @ xprod)
+        return xprod2 + xprod1
+
+    def get_rank(self):
+        return self.inv_eig.shape[0]
+
+    def get_zty(self):
+        return self.z_trans_y
+
+    def get_yty(self):
+        return float(self.y_trans_y)

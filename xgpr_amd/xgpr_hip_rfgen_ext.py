@@ -53,6 +53,11 @@ def _workspace(nbytes, device):
     return ws, C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel())
 
 
+def _sorf_ws(radem, width, inputArr):
+    nbytes = _LIB.xgpr_sorf_workspace_bytes(radem.shape[2], int(width), inputArr.element_size())
+    return _workspace(nbytes, inputArr.device)
+
+
 def _seqlens(seqlengths, device):
     """Host int32 array (validated by the library on the host) + its device copy."""
     if isinstance(seqlengths, torch.Tensor):
@@ -109,7 +114,7 @@ def hipRBFFeatureGen(inputArr, outputArr, radem, chiArr, fitIntercept):
     o = _dev(outputArr, "outputArr", torch.float64, 2)
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
-    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    ws, wp, wn = _sorf_ws(radem, inputArr.shape[1], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_rbf_feature_gen_{s}")(
         x, o, r, c, inputArr.shape[0], inputArr.shape[1], outputArr.shape[0], outputArr.shape[1],
         chiArr.shape[0], radem.shape[2], int(bool(fitIntercept)), wp, wn, _stream()))
@@ -125,7 +130,7 @@ def hipRBFGrad(inputArr, outputArr, gradArr, radem, chiArr, sigma, fitIntercept)
         raise TypeError("gradArr: expected shape (N, M, 1)")
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
-    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    ws, wp, wn = _sorf_ws(radem, inputArr.shape[1], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_rbf_grad_{s}")(
         x, o, g, r, c, inputArr.shape[0], inputArr.shape[1], outputArr.shape[0], outputArr.shape[1],
         gradArr.shape[0], gradArr.shape[1], chiArr.shape[0], radem.shape[2], float(sigma),
@@ -140,7 +145,7 @@ def hipConv1dFGen(inputArr, outputArr, radem, chiArr, seqlengths, convWidth, sca
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
     host, dev = _seqlens(seqlengths, inputArr.device)
-    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    ws, wp, wn = _sorf_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_conv1d_fgen_{s}")(
         x, o, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
         inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], chiArr.shape[0],
@@ -156,7 +161,7 @@ def hipConvGrad(inputArr, outputArr, radem, chiArr, seqlengths, gradArr, sigma, 
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
     host, dev = _seqlens(seqlengths, inputArr.device)
-    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    ws, wp, wn = _sorf_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_conv_grad_{s}")(
         x, o, g, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
         inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], gradArr.shape[0],
@@ -172,7 +177,7 @@ def hipConv1dMaxpool(inputArr, outputArr, radem, chiArr, seqlengths, convWidth):
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
     host, dev = _seqlens(seqlengths, inputArr.device)
-    ws, wp, wn = _workspace(_LIB.xgpr_rbf_workspace_bytes(radem.shape[2]), inputArr.device)
+    ws, wp, wn = _sorf_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_conv1d_maxpool_{s}")(
         x, o, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
         inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], chiArr.shape[0],
