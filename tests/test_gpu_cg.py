@@ -65,7 +65,9 @@ def test_g7_cg_iterates(kname, parms):
             # the 1e-5 bar; the sensitive pair is bounded.
             assert np.sort(errs)[-3] <= 1e-5 and errs.max() <= 2e-2, (ptag, errs)
         nl = min(len(losses), len(g[f"{kname}_{ptag}_losses"]))
-        assert np.allclose(losses[:nl], g[f"{kname}_{ptag}_losses"][:nl], rtol=1e-4 if pre is not None else 1e-2)
+        if pre is None:
+            nl = min(nl, 6)      # before the near-breakdown window
+        assert np.allclose(losses[:nl], g[f"{kname}_{ptag}_losses"][:nl], rtol=1e-4)
         # full solve to the reference's tolerance: same iteration count, same weights
         w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False)
         assert abs(niter - int(g[f"{kname}_{ptag}_niter"])) <= 1, (ptag, niter)

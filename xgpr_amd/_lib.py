@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxgpr_hip.so")
+# XGPR_HIP_LIB: development aid (ablation builds of the same library); never a fallback
+LIB_PATH = os.environ.get("XGPR_HIP_LIB", os.path.join(_HERE, "libxgpr_hip.so"))
 
 _vp, _l, _i, _d, _sz = C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_size_t
 

@@ -82,36 +82,9 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 __device__ __forceinline__ float as_f(int x) { return __builtin_bit_cast(float, x); }
 __device__ __forceinline__ int as_i(float x) { return __builtin_bit_cast(int, x); }
 
-// Rare path of sincos_f32 (|v| >= 2^18, inf, nan): double-precision Cody-Waite, or the
-// ocml functions for arguments whose quadrant index would not fit an int.
-__device__ __attribute__((noinline)) float2 sincos_slow(float v) {
-    if (fabsf(v) < 1.0e9f) {
-        double vd = (double)v;
-        double kd = __builtin_rint(vd * 0.63661977236758134308);
-        double r = __builtin_fma(kd, -1.57079632679489655800e+00, vd);
-        r = __builtin_fma(kd, -6.12323399573676603587e-17, r);
-        long q = (long)kd;
-        double sd, cd;
-        sd = sin(r); cd = cos(r);
-        double ss = (q & 1) ? cd : sd;
-        double cc = (q & 1) ? sd : cd;
-        if (q & 2) ss = -ss;
-        if ((q + 1) & 2) cc = -cc;
-        return make_float2((float)ss, (float)cc);
-    }
-    return make_float2(sinf(v), cosf(v));
-}
-
-// sin and cos of a float argument, <= 1.6 ulp each for |v| < 2^18 (max abs error 9.3e-8,
-// measured against double-precision libm over 4e7 arguments): Cody-Waite reduction by pi/2
-// in three fmas + the Cephes single-precision kernels on [-pi/4, pi/4].  The reference
-// evaluates glibc cosf/sinf (<1 ulp), so features agree to ~2 ulp(f32) * scale.
-__device__ __forceinline__ void sincos_f32(float v, float &s, float &c) {
-    float kf = __builtin_rintf(v * 0.6366197466850281f);
-    float r = __builtin_fmaf(kf, -1.5707963705062866f, v);
-    r = __builtin_fmaf(kf, 4.371138828673793e-08f, r);
-    r = __builtin_fmaf(kf, 1.7151245100058819e-15f, r);
-    int q = (int)kf;
+// Cephes single-precision sin / cos kernels on the reduced argument r in [-pi/4, pi/4],
+// quadrant q (v = q * pi/2 + r).
+__device__ __forceinline__ void sincos_poly(float r, int q, float &s, float &c) {
     float r2 = r * r;
     float ps = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2,
                               -1.6666654611e-1f), r2 * r, r);
@@ -121,10 +94,38 @@ __device__ __forceinline__ void sincos_f32(float v, float &s, float &c) {
     float cc = (q & 1) ? ps : pc;
     s = as_f(as_i(ss) ^ ((q & 2) << 30));
     c = as_f(as_i(cc) ^ (((q + 1) & 2) << 30));
-    if (__builtin_expect(!(fabsf(v) < 262144.0f), 0)) {
-        float2 sc = sincos_slow(v);
-        s = sc.x; c = sc.y;
-    }
+}
+
+// sin and cos of a float argument, <= 1.6 ulp each for |v| < 2^18 (max abs error 9.3e-8,
+// measured against double-precision libm over 4e7 arguments): Cody-Waite reduction by pi/2
+// in three fmas + the Cephes kernels.  The reference evaluates glibc cosf/sinf (<1 ulp), so
+// features agree to ~2 ulp(f32) * scale.
+__device__ __forceinline__ void sincos_f32_core(float v, float &s, float &c) {
+    float kf = __builtin_rintf(v * 0.6366197466850281f);
+    float r = __builtin_fmaf(kf, -1.5707963705062866f, v);
+    r = __builtin_fmaf(kf, 4.371138828673793e-08f, r);
+    r = __builtin_fmaf(kf, 1.7151245100058819e-15f, r);
+    sincos_poly(r, (int)kf, s, c);
+}
+
+// Rare path (2^18 <= |v|): the reduction is done in double precision (exact quadrant and a
+// reduced argument good to 1e-16 |v| for |v| < 2^31), call-free so that it costs the hot
+// kernels no registers.  Beyond 2^31 (un-normalised inputs: |chi * x| > 2e9), inf and nan
+// give NaN -- loudly -- where glibc would run Payne-Hanek.
+__device__ __forceinline__ void sincos_f32_big(float v, float &s, float &c) {
+    double vd = (double)v;
+    double kd = __builtin_rint(vd * 0.63661977236758134308);
+    double r = __builtin_fma(kd, -1.57079632679489655800e+00, vd);
+    r = __builtin_fma(kd, -6.12323399573676603587e-17, r);
+    sincos_poly((float)r, (int)((long)kd & 3), s, c);
+    if (!(fabsf(v) < 2147483648.0f)) { s = __builtin_nanf(""); c = s; }
+}
+
+constexpr float SINCOS_FAST_LIMIT = 262144.0f;
+
+__device__ __forceinline__ void sincos_f32(float v, float &s, float &c) {
+    sincos_f32_core(v, s, c);
+    if (__builtin_expect(!(fabsf(v) < SINCOS_FAST_LIMIT), 0)) sincos_f32_big(v, s, c);
 }
 
 template <typename T> struct Math;
@@ -413,26 +414,51 @@ template <int LOG2P> __device__ __forceinline__ void wave_fht(float (&v)[16], in
     }
 }
 
+// Scalar view of the packed sign masks: constant address space, so the (wave-uniform) loads
+// are s_load_dwordx16 into SGPRs and each mask is applied with one v_cndmask.
+typedef const __attribute__((address_space(4))) uint64_t *cmask_t;
+
+__device__ __forceinline__ cmask_t as_cmask(const uint64_t *p) { return (cmask_t)p; }
+
+// Inside a per-datapoint loop: stops the compiler from hoisting the 48 mask loads out of the
+// loop (96 live SGPRs would be spilled to VGPR lanes); re-reading 384 B from the scalar cache
+// per datapoint costs no vector-ALU issue slots.
+__device__ __forceinline__ cmask_t launder(cmask_t p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // three rounds of { x *= radem * norm ; FHT }.  mk points at this tile's first mask of
 // diagonal 0; diagonal s is MW masks further on.  For even log2(P) the normaliser is an
 // exact power of two and is folded into chi by the caller (exact), so only the sign flip
 // remains; for odd log2(P) the rounded constant is applied per round as the reference does.
 template <int LOG2P>
-__device__ __forceinline__ void wave_sorf(float (&v)[16], const uint64_t *__restrict__ mk, int MW, float nc, int lane) {
+__device__ __forceinline__ void wave_sorf(float (&v)[16], cmask_t mk, int MW, float nc, int lane) {
+    uint64_t m[16];
+    #pragma unroll
+    for (int r = 0; r < 16; r++) m[r] = mk[r];
     #pragma unroll
     for (int s = 0; s < 3; s++) {
         #pragma unroll
         for (int r = 0; r < 16; r++) {
-            uint64_t m = mk[s * MW + r];
             float t = (LOG2P & 1) ? v[r] * nc : v[r];
-            v[r] = __builtin_amdgcn_inverse_ballot_w64(m) ? -t : t;
+            v[r] = __builtin_amdgcn_inverse_ballot_w64(m[r]) ? -t : t;
+        }
+        if (s < 2) {
+            // next round's 16 masks: issued here, after this round's were consumed (the empty asm
+            // ties the loads to the data), so they arrive under the FHT and at most two rounds of
+            // masks are ever live in SGPRs
+            asm volatile("" : "+s"(mk) : "v"(v[0]));
+            #pragma unroll
+            for (int r = 0; r < 16; r++) m[r] = mk[(s + 1) * MW + r];
         }
         wave_fht<LOG2P>(v, lane);
     }
 }
 
 // load one datapoint (or k-mer window) into the wave tile: element (64 r + l) mod P, zero
-// padded from d up to P, replicated over the tile's 1024 / P transforms.
+// padded from d up to P, replicated over the tile's 1024 / P transforms.  The padded lanes
+// read element 0 and are zeroed by a select, so there is no branch around the loads.
 template <int LOG2P>
 __device__ __forceinline__ void wave_load(float (&v)[16], const float *__restrict__ xe, int d, int lane) {
     constexpr int P = 1 << LOG2P;
@@ -440,16 +466,42 @@ __device__ __forceinline__ void wave_load(float (&v)[16], const float *__restric
         constexpr int RP = P / 64;
         #pragma unroll
         for (int r = 0; r < RP; r++) {
-            int e = r * 64 + lane;
-            v[r] = e < d ? xe[e] : 0.0f;
+            const int e = r * 64 + lane;
+            const bool ok = e < d;
+            float t = xe[ok ? e : 0];
+            v[r] = ok ? t : 0.0f;
         }
         #pragma unroll
         for (int r = RP; r < 16; r++) v[r] = v[r & (RP - 1)];
     } else {
-        int e = lane & (P - 1);
-        float t = e < d ? xe[e] : 0.0f;
+        const int e = lane & (P - 1);
+        const bool ok = e < d;
+        float t = xe[ok ? e : 0];
+        t = ok ? t : 0.0f;
         #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = t;
+    }
+}
+
+// cos/sin of the 16 arguments of a tile.  The common path is branch-free; the rare large
+// arguments (|v| >= 2^18, inf, nan) are fixed up behind ONE wave-level test.
+__device__ __forceinline__ void tile_sincos(const float (&arg)[16], float (&sn)[16], float (&cs)[16]) {
+    bool big = false;
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        sincos_f32_core(arg[r], sn[r], cs[r]);
+        big |= !(fabsf(arg[r]) < SINCOS_FAST_LIMIT);
+    }
+    if (__builtin_expect(__any(big), 0)) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float s2, c2;
+            sincos_f32_big(arg[r], s2, c2);
+            const bool b = !(fabsf(arg[r]) < SINCOS_FAST_LIMIT);
+            sn[r] = b ? s2 : sn[r];
+            cs[r] = b ? c2 : cs[r];
+            __builtin_amdgcn_sched_barrier(0);   // cold path: one element at a time, no extra registers
+        }
     }
 }
 
@@ -473,21 +525,30 @@ __global__ __launch_bounds__(256) void wave_rbf_kernel(WaveArgs a) {
     const long item = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (long)blockIdx.x * 4;
     if (item >= a.n * a.nb) return;
     const long i = item / a.nb;
-    const int b = (int)(item % a.nb);
+    const int b = __builtin_amdgcn_readfirstlane((int)(item % a.nb));
     float v[16];
     wave_load<LOG2P>(v, a.x + i * a.row_stride, a.d, lane);
-    wave_sorf<LOG2P>(v, a.masks + (long)b * 16, a.MW, a.nc, lane);
+    wave_sorf<LOG2P>(v, as_cmask(a.masks + (long)b * 16), a.MW, a.nc, lane);
     const long f0 = (long)b * 1024 + lane;
-    double *orow = a.out + i * 2 * a.F;
+    const bool full = f0 - lane + 1024 <= a.F;      // wave-uniform: the whole tile is inside F
+    float arg[16], sn[16], cs[16];
     #pragma unroll
     for (int r = 0; r < 16; r++) {
         const long f = f0 + r * 64;
-        if (f < a.F) {
-            float prod = v[r] * (a.chi[f] * a.chi_scale);
-            float sn, cs;
-            sincos_f32(prod, sn, cs);
-            double2 val = make_double2(cs * a.scale, sn * a.scale);
-            *reinterpret_cast<double2 *>(orow + 2 * f) = val;
+        const float ch = a.chi[(full || f < a.F) ? f : 0];
+        arg[r] = v[r] * (ch * a.chi_scale);
+    }
+    tile_sincos(arg, sn, cs);
+    double *orow = a.out + i * 2 * a.F;
+    if (full) {
+        #pragma unroll
+        for (int r = 0; r < 16; r++)
+            *reinterpret_cast<double2 *>(orow + 2 * (f0 + r * 64)) = make_double2(cs[r] * a.scale, sn[r] * a.scale);
+    } else {
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long f = f0 + r * 64;
+            if (f < a.F) *reinterpret_cast<double2 *>(orow + 2 * f) = make_double2(cs[r] * a.scale, sn[r] * a.scale);
         }
     }
 }
@@ -500,7 +561,7 @@ __global__ __launch_bounds__(256) void wave_conv_kernel(WaveArgs a) {
     const long item = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (long)blockIdx.x * 4;
     if (item >= a.n * a.nb) return;
     const long i = item / a.nb;
-    const int b = (int)(item % a.nb);
+    const int b = __builtin_amdgcn_readfirstlane((int)(item % a.nb));
     const int nk = a.seqlen[i] - a.conv_width + 1;
     const long f0 = (long)b * 1024 + lane;
     float ch[16];
@@ -509,7 +570,7 @@ __global__ __launch_bounds__(256) void wave_conv_kernel(WaveArgs a) {
         const long f = f0 + r * 64;
         ch[r] = f < a.F ? a.chi[f] * a.chi_scale : 0.0f;
     }
-    const uint64_t *mk = a.masks + (long)b * 16;
+    cmask_t mk = as_cmask(a.masks + (long)b * 16);
     const float *xrow = a.x + i * a.row_stride;
     if constexpr (MAXPOOL) {
         float acc[16];
@@ -520,6 +581,7 @@ __global__ __launch_bounds__(256) void wave_conv_kernel(WaveArgs a) {
             acc[r] = f < a.F ? orow[f] : 0.0f;
         }
         for (int j = 0; j < nk; j++) {
+            mk = launder(mk);
             float v[16];
             wave_load<LOG2P>(v, xrow + (long)j * a.kmer_stride, a.d, lane);
             wave_sorf<LOG2P>(v, mk, a.MW, a.nc, lane);
@@ -539,15 +601,17 @@ __global__ __launch_bounds__(256) void wave_conv_kernel(WaveArgs a) {
         #pragma unroll
         for (int r = 0; r < 16; r++) { ac[r] = 0.0; as[r] = 0.0; }
         for (int j = 0; j < nk; j++) {
-            float v[16];
+            mk = launder(mk);
+            float v[16], sn[16], cs[16];
             wave_load<LOG2P>(v, xrow + (long)j * a.kmer_stride, a.d, lane);
             wave_sorf<LOG2P>(v, mk, a.MW, a.nc, lane);
             #pragma unroll
+            for (int r = 0; r < 16; r++) v[r] *= ch[r];
+            tile_sincos(v, sn, cs);
+            #pragma unroll
             for (int r = 0; r < 16; r++) {
-                float sn, cs;
-                sincos_f32(v[r] * ch[r], sn, cs);
-                ac[r] += (double)cs;
-                as[r] += (double)sn;
+                ac[r] += (double)cs[r];
+                as[r] += (double)sn[r];
             }
         }
         double rs = a.scale;
@@ -568,22 +632,51 @@ __global__ __launch_bounds__(256) void wave_conv_kernel(WaveArgs a) {
     }
 }
 
+// sum of a double over the 64 lanes, returned wave-uniform.  Rows of 16 lanes are reduced with
+// DPP moves (row_shr 8/4/2/1 on the two dwords + v_add_f64: short VALU chains, no LDS round
+// trips); the four row totals are read out of lanes 15, 31, 47, 63 and added in a fixed order.
+__device__ __forceinline__ double dpp_shr_f64(double x, const int ctrl_sel) {
+    int lo = __builtin_bit_cast(int2, x).x, hi = __builtin_bit_cast(int2, x).y;
+    int lo2, hi2;
+    if (ctrl_sel == 8) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); }
+    else if (ctrl_sel == 4) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); }
+    else if (ctrl_sel == 2) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); }
+    else { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); }
+    int2 r; r.x = lo2; r.y = hi2;
+    return __builtin_bit_cast(double, r);
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    int2 t = __builtin_bit_cast(int2, x);
+    int2 r;
+    r.x = __builtin_amdgcn_readlane(t.x, l);
+    r.y = __builtin_amdgcn_readlane(t.y, l);
+    return __builtin_bit_cast(double, r);
+}
+
 __device__ __forceinline__ double wave_sum(double u) {
-    #pragma unroll
-    for (int h = 32; h >= 1; h >>= 1) u += __shfl_xor(u, h);
-    return u;
+    // row_shr:n gives lane i the value of lane i-n (0.0 shifted in): after the four steps lane 15
+    // of every row holds the row total
+    u += dpp_shr_f64(u, 8);
+    u += dpp_shr_f64(u, 4);
+    u += dpp_shr_f64(u, 2);
+    u += dpp_shr_f64(u, 1);
+    return (readlane_f64(u, 15) + readlane_f64(u, 31)) + (readlane_f64(u, 47) + readlane_f64(u, 63));
 }
 
 // ---- fused CG matvec / z^T y.  A workgroup holds G datapoints in flight; datapoint slot g is
-// served by nb waves, wave (g, b) owning tile b = frequencies [1024 b, 1024 b + 1024): its
-// slice of v (MATVEC) and its f64 accumulators stay in registers for the whole launch while
-// the workgroup strides over its datapoints.  Per datapoint: SORF -> cos/sin (registers) ->
-// partial dot with v -> nb partials meet in LDS (one barrier, double-buffered) -> rank-1
-// update of the accumulators.  Z is never written.  At the end every slot writes its
-// accumulators as one slab wpart[slot, :]; reduce_slabs_kernel adds the slabs in slot order.
+// served by nb waves, wave (g, b) owning tile b = frequencies [1024 b, 1024 b + 1024): its f64
+// accumulators stay in registers for the whole launch while the workgroup strides over its
+// datapoints; the vector v (MATVEC) sits in LDS as (cos, sin) pairs, shared by the G slots.
+// Per datapoint: SORF -> cos/sin (registers) -> partial dot with v -> nb partials meet in LDS
+// (one barrier, double-buffered) -> rank-1 update of the accumulators.  Z is never written.
+// At the end every slot writes its accumulators as one slab wpart[slot, :];
+// reduce_slabs_kernel adds the slabs in slot order (deterministic).
 template <int LOG2P, bool MATVEC>
 __global__ __launch_bounds__(512, 2) void wave_ztz_kernel(WaveArgs a) {
-    __shared__ double part[2][16];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *pv = reinterpret_cast<double2 *>(smem);                       // [nb * 1024] (cos, sin) of v
+    double *part = reinterpret_cast<double *>(smem + (MATVEC ? (size_t)a.nb * 1024 * 16 : 0));   // [2][16]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = w % a.nb;
@@ -592,55 +685,66 @@ __global__ __launch_bounds__(512, 2) void wave_ztz_kernel(WaveArgs a) {
     const long nslots = (long)gridDim.x * a.G;
     const long iters = (a.n + nslots - 1) / nslots;
     const long f0 = (long)b * 1024 + lane;
-    const uint64_t *mk = a.masks + (long)b * 16;
+    cmask_t mk = as_cmask(a.masks + (long)b * 16);
 
+    if (MATVEC) {
+        for (long f = threadIdx.x; f < (long)a.nb * 1024; f += blockDim.x)
+            pv[f] = f < a.F ? *reinterpret_cast<const double2 *>(a.vec + 2 * f) : make_double2(0.0, 0.0);
+        __syncthreads();
+    }
     float ch[16];
-    double pc[16], ps[16], ac[16], as[16];
+    double ac[16], as[16];
     #pragma unroll
     for (int r = 0; r < 16; r++) {
         const long f = f0 + r * 64;
-        const bool ok = f < a.F;
-        ch[r] = ok ? a.chi[f] * a.chi_scale : 0.0f;
+        ch[r] = f < a.F ? a.chi[f] * a.chi_scale : 0.0f;
         ac[r] = 0.0; as[r] = 0.0;
-        if (MATVEC) {
-            double2 p = ok ? *reinterpret_cast<const double2 *>(a.vec + 2 * f) : make_double2(0.0, 0.0);
-            pc[r] = p.x; ps[r] = p.y;
-        }
     }
     // Z[:, 0] = 1 (kernel_baseclass.py:296-297): feature (f = 0, cos) is 1 / scale before scaling
     const bool icpt = a.fit_intercept && b == 0 && lane == 0;
     const double inv_scale = 1.0 / a.scale;
     const double s2 = a.scale * a.scale;
+    const double2 *pw = pv + (long)b * 1024 + lane;
 
+    float v[16];
+    if (slot < a.n) wave_load<LOG2P>(v, a.x + slot * a.row_stride, a.d, lane);
     for (long it = 0; it < iters; it++) {
         const long row = it * nslots + slot;
         const bool active = row < a.n;
         float cs[16], sn[16];
-        double u = 0.0;
+        mk = launder(mk);
         if (active) {
-            float v[16];
-            wave_load<LOG2P>(v, a.x + row * a.row_stride, a.d, lane);
             wave_sorf<LOG2P>(v, mk, a.MW, a.nc, lane);
             #pragma unroll
-            for (int r = 0; r < 16; r++) sincos_f32(v[r] * ch[r], sn[r], cs[r]);
+            for (int r = 0; r < 16; r++) v[r] *= ch[r];
+            tile_sincos(v, sn, cs);
         } else {
             #pragma unroll
             for (int r = 0; r < 16; r++) { cs[r] = 0.0f; sn[r] = 0.0f; }
         }
-        double c0 = icpt ? inv_scale : (double)cs[0];
+        // next datapoint's x: issued before the f64 work so its latency is covered
+        const long nrow = row + nslots;
+        if (nrow < a.n) wave_load<LOG2P>(v, a.x + nrow * a.row_stride, a.d, lane);
+        const double c0 = (icpt && active) ? inv_scale : (double)cs[0];
+        double u;
         if (MATVEC) {
-            u = __builtin_fma(c0, pc[0], u);
-            u = __builtin_fma((double)sn[0], ps[0], u);
+            double u0 = 0.0, u1 = 0.0;
+            {
+                const double2 p = pw[0];
+                u0 = __builtin_fma(c0, p.x, u0);
+                u1 = __builtin_fma((double)sn[0], p.y, u1);
+            }
             #pragma unroll
             for (int r = 1; r < 16; r++) {
-                u = __builtin_fma((double)cs[r], pc[r], u);
-                u = __builtin_fma((double)sn[r], ps[r], u);
+                const double2 p = pw[r * 64];
+                u0 = __builtin_fma((double)cs[r], p.x, u0);
+                u1 = __builtin_fma((double)sn[r], p.y, u1);
             }
-            u = wave_sum(u);
-            if (lane == 0) part[it & 1][w] = u;
+            u = wave_sum(u0 + u1);
+            if (lane == 0) part[(it & 1) * 16 + w] = u;
             __syncthreads();
             double t = 0.0;
-            for (int bb = 0; bb < a.nb; bb++) t += part[it & 1][g * a.nb + bb];
+            for (int bb = 0; bb < a.nb; bb++) t += part[(it & 1) * 16 + g * a.nb + bb];
             u = t * s2;
         } else {
             u = active ? a.vec[row] * a.scale : 0.0;   // y[row] * scale
@@ -963,7 +1067,7 @@ int conv_impl(const T *x, double *out, double *grad, float *outf, const int8_t *
     return launch_generic_sorf<T, MODE_MAXPOOL>(a, workspace, wbytes, st);
 }
 
-constexpr long ZTZ_MAX_SLABS = 1024;
+constexpr long ZTZ_MAX_SLABS = 2048;
 
 template <bool MATVEC>
 int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double *vec, double *w_out, long n,
@@ -988,7 +1092,11 @@ int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double
     a.wpart = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(workspace) + mb);
     a.n = n; a.row_stride = d; a.F = num_freqs; a.d = (int)d;
     a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
+    // 4 waves per workgroup where possible (two workgroups per CU = 2 waves per SIMD; the
+    // per-datapoint barrier then only joins the nb waves of one datapoint), each with its own
+    // copy of v in LDS
     a.G = a.nb >= 4 ? 1 : 4 / a.nb;
+    if ((long)a.G > n) a.G = (int)n;
     a.fit_intercept = fit_intercept;
     a.scale = rbf_scale<float>(num_freqs, fit_intercept);
     const int lg = ilog2(P);
@@ -1003,7 +1111,14 @@ int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double
     if (nblocks > max_by_rows) nblocks = max_by_rows;
     if (nblocks * a.G > ZTZ_MAX_SLABS) nblocks = ZTZ_MAX_SLABS / a.G;
     const long nslabs = nblocks * a.G;
-#define CALL_ZTZ(LG) hipLaunchKernelGGL((wave_ztz_kernel<LG, MATVEC>), dim3((unsigned)nblocks), dim3(waves_per_wg * 64), 0, st, a)
+    const size_t lds = (MATVEC ? (size_t)a.nb * 1024 * 16 : 0) + 2 * 16 * sizeof(double);
+#define CALL_ZTZ(LG)                                                                                        \
+    {                                                                                                       \
+        auto kern = wave_ztz_kernel<LG, MATVEC>;                                                            \
+        int rc2 = allow_big_lds(kern, lds);                                                                 \
+        if (rc2) return rc2;                                                                                \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(waves_per_wg * 64), lds, st, a);            \
+    }
     DISPATCH_LOG2P(lg, CALL_ZTZ)
 #undef CALL_ZTZ
     HIP_TRY(hipGetLastError(), "wave_ztz_kernel launch");
