@@ -192,6 +192,17 @@ def main():
 
     if comm.rank == 0:
         n_local = hi - lo
+        # HBM bytes per launch of the dominant kernel from the PMC counters (collected in separate
+        # rocprofv3 --pmc passes of this same command, corrected as MI355X_MICROARCH.md prescribes;
+        # see profiles/r1_pmc_traffic.json) -- only quoted when it was measured on this configuration
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            c = pm["config"]
+            if (c["rows_per_gpu"], c["dim"], c["rffs"]) == (n_local, d, m):
+                traffic = pm["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         alg_bytes = 4.0 * d * n_local                   # 4*d bytes per row, X read once
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         fg_bytes = (4.0 * d + 8.0 * m) * fg_rows
@@ -214,7 +225,7 @@ def main():
                        "rows_per_gpu": n_local, "lambda": 0.1, "sigma": 1.0},
             "roofline": {"kernel": "wave_ztz_kernel<10, true> (+ pack_radem, reduce_slabs)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kern_ms,
+                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
                          "note": "HBM traffic of this kernel is only the X read; the binding resource is VALU "
                                  "(butterflies + sincos), see DESIGN.md"},
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
