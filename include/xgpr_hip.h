@@ -162,6 +162,29 @@ int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const do
                  long radem_shape2, int fit_intercept,
                  void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- fused CG vector updates for one right-hand side: the per-iteration arithmetic of
+ * CPU/GPU_ConjugateGrad.fit (src/xGPR/fitting_toolkit/cg_tools.py:255-274 / :108-127) between
+ * the matvec and the next search direction, as two single-workgroup kernels.  All vectors are
+ * float64 [M] on the device; scal is float64 [4] = { r.z, alpha, err, beta }.
+ *   step1: w += lam2 * p (w arrives holding the all-reduced Z^T Z p); alpha = (r.z)/(p.w);
+ *          x += alpha p; r_next = r - alpha w; err = |r| / init_norm   (cg_tools.py:256-265)
+ *   precond_scale: t[j] = (inv_eig[j] * prefactor - 1) * t[j]  -- the diagonal between the two
+ *          U products of RandNysPreconditioner.batch_matvec (rand_nys_preconditioners.py:66-72)
+ *   step2: beta = (r_next.z_next)/(r.z); p_next = z_next + beta p     (cg_tools.py:271-274) */
+int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next,
+                      const double *z, double *scal, double lam2, double init_norm, long M, void *stream);
+int xgpr_precond_scale_f64(double *t, const double *inv_eig, double prefactor, long rank, void *stream);
+int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *p, double *p_next,
+                      double *scal, long M, void *stream);
+
+/* ---- RandNysPreconditioner.batch_matvec for one right-hand side
+ * (src/xGPR/preconditioners/rand_nys_preconditioners.py:66-72):
+ *   z = U (inv_eig * prefactor .* U^T r) + (r - U U^T r),   U [M, rank] float64 row-major. */
+size_t xgpr_precond_apply_workspace_bytes(long rank);
+int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefactor, const double *r,
+                           double *z, long M, long rank, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* ---- self test of the cross-lane butterfly stages the wave-level FHT is built on: for each
  * of the 6 lane strides h = 1, 2, 4, 8, 16, 32 runs one stage on v[r] = lane + 64 r
  * (r = 0..15) and writes the result to out[6][16][64] (int32, device).  Expected:

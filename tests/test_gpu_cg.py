@@ -115,3 +115,39 @@ def test_conv_kernel_cg_matches_oracle(oracle):
     wref, nref, _, _ = orc.cg_fit_lib_internal(okern, ods, 1e-9, 300, None)
     assert abs(niter - nref) <= 1
     assert rel(w, wref) < 1e-5
+
+
+def test_precond_apply_and_fused_cg_steps():
+    """hipPrecondApply == RandNysPreconditioner.batch_matvec (rand_nys_preconditioners.py:66-72);
+    hipCGStep1/2 == the vector updates of cg_tools.py:256-274 -- float64, 1e-12 relative."""
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(3)
+    for m, rank in [(8192, 512), (1000, 37), (300, 64)]:
+        u, _ = np.linalg.qr(rng.standard_normal((m, rank)))
+        inv_eig = 1.0 / rng.uniform(0.1, 5.0, size=rank)
+        pref = 0.37
+        r = rng.standard_normal(m)
+        ref = u @ (inv_eig * pref * (u.T @ r)) + (r - u @ (u.T @ r))
+        z = torch.zeros(m, dtype=torch.float64, device=DEV)
+        ext.hipPrecondApply(torch.from_numpy(u).to(DEV), torch.from_numpy(inv_eig).to(DEV), pref,
+                            torch.from_numpy(r).to(DEV), z)
+        assert rel(z, ref) < 1e-12
+        w, p, x, zz = (rng.standard_normal(m) for _ in range(4))
+        lam2, init_norm = 0.01, 3.3
+        wd, pd, xd, rd, zd = (torch.from_numpy(a.copy()).to(DEV) for a in (w, p, x, r, zz))
+        rn = torch.empty(m, dtype=torch.float64, device=DEV)
+        scal = torch.zeros(4, dtype=torch.float64, device=DEV)
+        ext.hipCGStep1(wd, pd, xd, rd, rn, zd, scal, lam2, init_norm)
+        w2 = w + lam2 * p
+        rz = (r * zz).sum()
+        alpha = rz / (p * w2).sum()
+        assert rel(wd, w2) < 1e-14 and rel(xd, x + alpha * p) < 1e-12 and rel(rn, r - alpha * w2) < 1e-12
+        s = scal.cpu().numpy()
+        assert np.isclose(s[0], rz, rtol=1e-12) and np.isclose(s[1], alpha, rtol=1e-12)
+        assert np.isclose(s[2], np.linalg.norm(r) / init_norm, rtol=1e-12)
+        znext = rng.standard_normal(m)
+        pn = torch.empty(m, dtype=torch.float64, device=DEV)
+        ext.hipCGStep2(rn, torch.from_numpy(znext).to(DEV), pd, pn, scal)
+        beta = ((r - alpha * w2) * znext).sum() / rz
+        assert rel(pn, znext + beta * p) < 1e-12
+        assert np.isclose(scal.cpu().numpy()[3], beta, rtol=1e-10)

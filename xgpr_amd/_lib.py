@@ -33,11 +33,16 @@ SIGNATURES = {
     "xgpr_conv1d_maxpool_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_ztz_matvec_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_zty_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_cg_step1_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _l, _vp],
+    "xgpr_precond_scale_f64": [_vp, _vp, _d, _l, _vp],
+    "xgpr_cg_step2_f64": [_vp, _vp, _vp, _vp, _vp, _l, _vp],
+    "xgpr_precond_apply_f64": [_vp, _vp, _d, _vp, _vp, _l, _l, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
 }
 SIZE_FUNCS = {
     "xgpr_rbf_workspace_bytes": [_l],
     "xgpr_sorf_workspace_bytes": [_l, _l, _i],
+    "xgpr_precond_apply_workspace_bytes": [_l],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
 }
 STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch"]

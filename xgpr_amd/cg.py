@@ -72,12 +72,102 @@ class ConjugateGrad:
             kernel.ztz_matvec(xs, vec[:, j].contiguous(), tmp, self._ws)
             matvec[:, j] = tmp
 
+    def _ztz(self, dataset, kernel, vec, out):
+        """out <- sum over ranks of Z^T (Z vec) for one right-hand side (fused kernel +
+        all-reduce); lambda^2 vec is added by the caller."""
+        xs = dataset.scaled_x(kernel.hyperparams[1])
+        if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != xs.device:
+            self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=xs.device)
+        kernel.ztz_matvec(xs, vec, out, self._ws)
+        self.comm.all_reduce_(out)
+
+    def _fit_one_rhs_device(self, dataset, kernel, preconditioner, resid, maxiter, tol, verbose, trace):
+        """The k = 1 regression solve on the device with the vector updates of
+        cg_tools.py:255-274 fused into two small kernels (hipCGStep1 / hipCGStep2) and the
+        preconditioner apply (hipPrecondApply) written as r + U ((inv_eig * prefactor - 1) .* (U^T r)).  Same
+        recurrences, same lagging error, same iteration count as ``fit``; the host only reads one
+        scalar (err) per iteration, and reads it *after* queueing the next matvec, so the device
+        never waits for the host."""
+        from . import xgpr_hip_rfgen_ext as ext
+        dev = resid.device
+        m = resid.shape[0]
+        f64 = dict(dtype=torch.float64, device=dev)
+        r = [resid[:, 0, 0].clone(), torch.empty(m, **f64)]
+        z = [torch.empty(m, **f64), torch.empty(m, **f64)]
+        p = [torch.empty(m, **f64), torch.empty(m, **f64)]
+        x_k = torch.zeros(m, **f64)
+        w = torch.zeros(m, **f64)
+        scal = torch.zeros(4, **f64)
+        init_norm = float(torch.linalg.norm(r[0]).item())
+        lam2 = float(kernel.get_lambda()) ** 2
+        if preconditioner is not None:
+            u_mat, inv_eig, pref = preconditioner.u_mat, preconditioner.inv_eig, preconditioner.prefactor
+            pws = torch.empty(ext.precond_workspace_bytes(u_mat.shape[1]), dtype=torch.uint8, device=dev)
+
+        def precond(src, dst):
+            if preconditioner is None:
+                dst.copy_(src)
+            else:
+                ext.hipPrecondApply(u_mat, inv_eig, pref, src, dst, pws)
+
+        precond(r[0], z[0])
+        p[0].copy_(z[0])
+        err_host = torch.zeros(maxiter, dtype=torch.float64).pin_memory()
+        events = []
+        losses, converged = [], False
+        cur, nxt = 0, 1
+        done = 0            # iterations fully queued
+        checked = 0         # iterations whose error the host has read
+        last_err = float("inf")
+
+        def read_err(i):
+            events[i].synchronize()
+            return float(err_host[i])
+
+        for niter in range(maxiter):
+            # near convergence read the pending error first (no wasted matvec); otherwise queue
+            # this iteration's matvec before looking at the previous error
+            if checked < done and last_err < 100.0 * tol:
+                last_err = read_err(checked); losses.append(last_err); checked += 1
+                if last_err < tol:
+                    converged = True
+                    break
+            self._ztz(dataset, kernel, p[cur], w)
+            if checked < done:
+                last_err = read_err(checked); losses.append(last_err); checked += 1
+                if last_err < tol:
+                    converged = True
+                    break
+            ext.hipCGStep1(w, p[cur], x_k, r[cur], r[nxt], z[cur], scal, lam2, init_norm)
+            precond(r[nxt], z[nxt])
+            ext.hipCGStep2(r[nxt], z[nxt], p[cur], p[nxt], scal)
+            err_host[niter:niter + 1].copy_(scal[2:3], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            events.append(ev)
+            done += 1
+            if trace is not None:
+                trace.setdefault("x_k", []).append(x_k.clone()[:, None])
+                trace.setdefault("alpha", []).append(scal[1:2].clone())
+                trace.setdefault("beta", []).append(scal[3:4].clone())
+            cur, nxt = nxt, cur
+            if niter % 5 == 0 and verbose and self.comm.rank == 0:
+                print(f"{niter} iterations complete.")
+        while checked < done:
+            last_err = read_err(checked); losses.append(last_err); checked += 1
+            if last_err < tol:
+                converged = True
+        return x_k, converged, done, losses
+
     def fit(self, dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, verbose=True,
             nmll_settings=False, trace=None):
         """cg_tools.py:203-302.  ``resid`` is [M, 2, k] float64 with column 0 holding the
         right-hand side; starting weights are zero.  Returns (x_k, converged, niter, losses),
         or (x_k, alphas, betas) with ``nmll_settings``."""
         dev = resid.device
+        if (resid.shape[2] == 1 and not nmll_settings and dev.type == "cuda" and kernel.fused_ok()
+                and (preconditioner is None or hasattr(preconditioner, "u_mat"))):
+            return self._fit_one_rhs_device(dataset, kernel, preconditioner, resid, maxiter, tol, verbose, trace)
         converged = False
         target = resid[:, 0, :].clone()
         init_norms = torch.linalg.norm(target, dim=0)

@@ -790,6 +790,104 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double *__restr
     if (ph == 0 && m < M) w_out[m] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
+// ------------------------------------------------------------------------------------
+// CG vector updates for one right-hand side (fitting_toolkit/cg_tools.py:255-274), fused into
+// two single-workgroup kernels: M is only 10^3..10^5, so one workgroup reduces and updates the
+// whole vector in a few microseconds, deterministically, instead of ~20 library launches.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double *red /* [16] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();               // red may still be read from a previous call
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; i++) t += red[i];
+    return t;
+}
+
+// step 1 (cg_tools.py:256-265): w += lambda^2 p ; alpha = (r.z)/(p.w) ; x += alpha p ;
+// r_next = r - alpha w ; err = |r| / |r_0|  (the lagging error, from the CURRENT residual).
+// scal[0] = r.z, scal[1] = alpha, scal[2] = err.
+__global__ __launch_bounds__(1024) void cg_step1_kernel(double *w, const double *__restrict__ p, double *x,
+                                                        const double *__restrict__ r, double *r_next,
+                                                        const double *__restrict__ z, double *scal, double lam2,
+                                                        double init_norm, long M) {
+    __shared__ double red[16];
+    double rz = 0.0, pw = 0.0, rr = 0.0;
+    for (long i = threadIdx.x; i < M; i += blockDim.x) {
+        const double pi = p[i], ri = r[i];
+        const double wi = w[i] + lam2 * pi;
+        w[i] = wi;
+        rz += ri * z[i];
+        pw += pi * wi;
+        rr += ri * ri;
+    }
+    rz = block_sum(rz, red);
+    pw = block_sum(pw, red);
+    rr = block_sum(rr, red);
+    const double alpha = rz / pw;
+    for (long i = threadIdx.x; i < M; i += blockDim.x) {
+        x[i] += alpha * p[i];
+        r_next[i] = r[i] - alpha * w[i];
+    }
+    if (threadIdx.x == 0) { scal[0] = rz; scal[1] = alpha; scal[2] = sqrt(rr) / init_norm; }
+}
+
+// between the steps: z_next = r_next + U ((inv_eig * prefactor - 1) .* (U^T r_next)) is two library
+// GEMVs (rand_nys_preconditioners.py:66-72 with the two U products merged); this kernel scales the
+// rank-sized vector in between: t[j] = (inv_eig[j] * prefactor - 1) * t[j].
+__global__ void precond_scale_kernel(double *t, const double *__restrict__ inv_eig, double prefactor, long rank) {
+    long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < rank) t[j] = (inv_eig[j] * prefactor - 1.0) * t[j];
+}
+
+// step 2 (cg_tools.py:271-274): beta = (r_next.z_next)/(r.z) ; p_next = z_next + beta p.  scal[3] = beta.
+__global__ __launch_bounds__(1024) void cg_step2_kernel(const double *__restrict__ r_next, const double *__restrict__ z_next,
+                                                        const double *__restrict__ p, double *p_next, double *scal, long M) {
+    __shared__ double red[16];
+    double rz = 0.0;
+    for (long i = threadIdx.x; i < M; i += blockDim.x) rz += r_next[i] * z_next[i];
+    rz = block_sum(rz, red);
+    const double beta = rz / scal[0];
+    for (long i = threadIdx.x; i < M; i += blockDim.x) p_next[i] = z_next[i] + beta * p[i];
+    if (threadIdx.x == 0) scal[3] = beta;
+}
+
+// ------------------------------------------------------------------------------------
+// Preconditioner apply for one right-hand side (rand_nys_preconditioners.py:66-72):
+//   z = U (inv_eig * prefactor .* U^T r) + (r - U U^T r) = r + U ((inv_eig * prefactor - 1) .* (U^T r)),
+// U [M, rank] float64 row-major.  Two HBM/MALL-bound passes over U (33.5 MB at M = 8192, rank = 512):
+// (1) per-row-block partial column sums, (2) slab reduce (shared with the matvec), (3) one wave
+// per row: z_i = r_i + U_i . s.  The library GEMV these replace ran at 0.24 ms per product.
+// ------------------------------------------------------------------------------------
+constexpr int PRE_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void precond_utr_kernel(const double *__restrict__ u, const double *__restrict__ r,
+                                                          double *part, long M, long rank) {
+    const long rows_per = (M + gridDim.x - 1) / gridDim.x;
+    const long i0 = (long)blockIdx.x * rows_per;
+    const long i1 = i0 + rows_per < M ? i0 + rows_per : M;
+    for (long j = threadIdx.x; j < rank; j += blockDim.x) {
+        double acc = 0.0;
+        for (long i = i0; i < i1; i++) acc = __builtin_fma(u[i * rank + j], r[i], acc);
+        part[(long)blockIdx.x * rank + j] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void precond_uz_kernel(const double *__restrict__ u, const double *__restrict__ t,
+                                                         const double *__restrict__ inv_eig, double prefactor,
+                                                         const double *__restrict__ r, double *z, long M, long rank) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const double *ur = u + row * rank;
+    double acc = 0.0;
+    for (long j = lane; j < rank; j += 64) acc = __builtin_fma(ur[j], (inv_eig[j] * prefactor - 1.0) * t[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) z[row] = r[row] + acc;
+}
+
 // ---- self test of the cross-lane stages: v[r] = lane + 64 r, one stage of stride H,
 // registers 0 and 1 written out.  Expected: bit H of lane clear -> 2 lane + H + 128 r, set -> -H.
 __global__ void selftest_kernel(int32_t *out) {
@@ -1247,6 +1345,49 @@ int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const do
                  size_t workspace_bytes, void *stream) {
     return ztz_impl<false>(x, radem, chi, y, zty_out, n, d, num_rffs, num_freqs, radem_shape2, fit_intercept, workspace,
                            workspace_bytes, stream);
+}
+
+int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next, const double *z,
+                      double *scal, double lam2, double init_norm, long M, void *stream) {
+    if (M <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    hipLaunchKernelGGL(cg_step1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, p, x, r, r_next, z, scal, lam2,
+                       init_norm, M);
+    HIP_TRY(hipGetLastError(), "cg_step1_kernel launch");
+    return 0;
+}
+int xgpr_precond_scale_f64(double *t, const double *inv_eig, double prefactor, long rank, void *stream) {
+    if (rank <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    hipLaunchKernelGGL(precond_scale_kernel, dim3((unsigned)((rank + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t,
+                       inv_eig, prefactor, rank);
+    HIP_TRY(hipGetLastError(), "precond_scale_kernel launch");
+    return 0;
+}
+int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *p, double *p_next, double *scal, long M,
+                      void *stream) {
+    if (M <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    hipLaunchKernelGGL(cg_step2_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r_next, z_next, p, p_next, scal, M);
+    HIP_TRY(hipGetLastError(), "cg_step2_kernel launch");
+    return 0;
+}
+
+size_t xgpr_precond_apply_workspace_bytes(long rank) { return (size_t)(PRE_BLOCKS + 1) * rank * sizeof(double); }
+int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefactor, const double *r, double *z,
+                           long M, long rank, void *workspace, size_t workspace_bytes, void *stream) {
+    if (M <= 0 || rank <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (!workspace || workspace_bytes < xgpr_precond_apply_workspace_bytes(rank) || !aligned16(workspace))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_precond_apply_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    double *part = reinterpret_cast<double *>(workspace);
+    double *t = part + (size_t)PRE_BLOCKS * rank;
+    const int nb = (int)(M < PRE_BLOCKS ? M : PRE_BLOCKS);
+    hipLaunchKernelGGL(precond_utr_kernel, dim3(nb), dim3(256), 0, st, u, r, part, M, rank);
+    HIP_TRY(hipGetLastError(), "precond_utr_kernel launch");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((rank + 63) / 64)), dim3(256), 0, st, part, t, rank, (long)nb);
+    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    hipLaunchKernelGGL(precond_uz_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, u, t, inv_eig, prefactor, r, z,
+                       M, rank);
+    HIP_TRY(hipGetLastError(), "precond_uz_kernel launch");
+    return 0;
 }
 
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {

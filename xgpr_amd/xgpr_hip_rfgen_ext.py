@@ -222,6 +222,55 @@ def hipZtY(inputArr, radem, chiArr, yvec, outVec, fitIntercept, workspace=None):
         C.c_size_t(workspace.numel()), _stream()))
 
 
+def hipCGStep1(w, p, x, r, r_next, z, scal, lam2, init_norm):
+    """cg_tools.py:256-265 for one right-hand side (see include/xgpr_hip.h)."""
+    for name, t in (("w", w), ("p", p), ("x", x), ("r", r), ("r_next", r_next), ("z", z)):
+        _dev(t, name, torch.float64, 1)
+    _dev(scal, "scal", torch.float64, 1)
+    return _lib.check(_LIB.xgpr_cg_step1_f64(
+        C.c_void_p(w.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(r.data_ptr()),
+        C.c_void_p(r_next.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(scal.data_ptr()), float(lam2),
+        float(init_norm), w.shape[0], _stream()))
+
+
+def hipPrecondScale(t, inv_eig, prefactor):
+    _dev(t, "t", torch.float64, 1)
+    _dev(inv_eig, "inv_eig", torch.float64, 1)
+    return _lib.check(_LIB.xgpr_precond_scale_f64(C.c_void_p(t.data_ptr()), C.c_void_p(inv_eig.data_ptr()),
+                                                  float(prefactor), t.shape[0], _stream()))
+
+
+def hipCGStep2(r_next, z_next, p, p_next, scal):
+    """cg_tools.py:271-274 for one right-hand side."""
+    for name, t in (("r_next", r_next), ("z_next", z_next), ("p", p), ("p_next", p_next)):
+        _dev(t, name, torch.float64, 1)
+    return _lib.check(_LIB.xgpr_cg_step2_f64(
+        C.c_void_p(r_next.data_ptr()), C.c_void_p(z_next.data_ptr()), C.c_void_p(p.data_ptr()),
+        C.c_void_p(p_next.data_ptr()), C.c_void_p(scal.data_ptr()), r_next.shape[0], _stream()))
+
+
+def hipPrecondApply(u_mat, inv_eig, prefactor, rvec, zvec, workspace=None):
+    """RandNysPreconditioner.batch_matvec for one right-hand side
+    (preconditioners/rand_nys_preconditioners.py:66-72): zvec <- P^-1 rvec."""
+    _dev(u_mat, "u_mat", torch.float64, 2)
+    _dev(inv_eig, "inv_eig", torch.float64, 1)
+    _dev(rvec, "rvec", torch.float64, 1)
+    _dev(zvec, "zvec", torch.float64, 1)
+    if u_mat.shape[0] != rvec.shape[0] or u_mat.shape[1] != inv_eig.shape[0] or zvec.shape[0] != rvec.shape[0]:
+        raise TypeError("hipPrecondApply: shapes do not match")
+    need = _LIB.xgpr_precond_apply_workspace_bytes(u_mat.shape[1])
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=u_mat.device)
+    return _lib.check(_LIB.xgpr_precond_apply_f64(
+        C.c_void_p(u_mat.data_ptr()), C.c_void_p(inv_eig.data_ptr()), float(prefactor),
+        C.c_void_p(rvec.data_ptr()), C.c_void_p(zvec.data_ptr()), u_mat.shape[0], u_mat.shape[1],
+        C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
+
+
+def precond_workspace_bytes(rank):
+    return int(_LIB.xgpr_precond_apply_workspace_bytes(rank))
+
+
 def ztz_workspace_bytes(num_rffs, radem_shape2):
     return int(_LIB.xgpr_ztz_matvec_workspace_bytes(num_rffs, radem_shape2))
 
