@@ -28,7 +28,7 @@
 #include <stdio.h>
 #include <string>
 
-#include "../../include/xgpr_hip.h"
+#include "/root/repo/include/xgpr_hip.h"
 
 namespace {
 

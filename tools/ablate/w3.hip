@@ -28,7 +28,7 @@
 #include <stdio.h>
 #include <string>
 
-#include "../../include/xgpr_hip.h"
+#include "/root/repo/include/xgpr_hip.h"
 
 namespace {
 
@@ -781,7 +781,7 @@ __device__ __forceinline__ double wave_sum(double u) {
 // At the end every slot writes its accumulators as one slab wpart[slot, :];
 // reduce_slabs_kernel adds the slabs in slot order (deterministic).
 template <int LOG2P, bool MATVEC, bool TPREQ>
-__global__ __launch_bounds__(512, 2) void wave_ztz_kernel(WaveArgs a) {
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3,3))) void wave_ztz_kernel(WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool TP = TPREQ && LOG2P >= 7;
     double2 *pv = reinterpret_cast<double2 *>(smem);                       // [nb * 1024] (cos, sin) of v
@@ -1305,7 +1305,7 @@ int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double
     a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
     // 8 waves per workgroup where possible (2 per SIMD, the register budget of this kernel): the
     // G datapoint slots of a workgroup share one copy of v in LDS
-    a.G = a.nb >= 8 ? 1 : 8 / a.nb;
+    a.G = a.nb >= 12 ? 1 : 12 / a.nb;
     if ((long)a.G > n) a.G = (int)n;
     a.fit_intercept = fit_intercept;
     a.scale = rbf_scale<float>(num_freqs, fit_intercept);
@@ -1315,7 +1315,7 @@ int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double
     if (rc) return rc;
 
     const int waves_per_wg = a.nb * a.G;
-    const int wg_per_cu = 8 / waves_per_wg > 0 ? 8 / waves_per_wg : 1;     // 2 waves per SIMD
+    const int wg_per_cu = 12 / waves_per_wg > 0 ? 12 / waves_per_wg : 1;     // 2 waves per SIMD
     long nblocks = (long)device_cus() * wg_per_cu;
     const long max_by_rows = (n + a.G - 1) / a.G;
     if (nblocks > max_by_rows) nblocks = max_by_rows;
