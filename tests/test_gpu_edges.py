@@ -1,0 +1,105 @@
+"""Edge cases the reference's tests exercise or imply: minimal shapes, ragged sequence lengths,
+a single k-mer, widths that straddle the fast-path limits, large-argument cos/sin, empty input."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("n,d,rffs", [(1, 1, 2), (1, 2, 2), (3, 1, 10), (2, 5, 2), (1, 1024, 8192), (65537, 4, 8)])
+def test_minimal_shapes(oracle, n, d, rffs):
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(n + d)
+    radem, chi = orc.draw_sorf_params(rffs, d, 3)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    ref = np.zeros((n, rffs))
+    oracle.cpuRBFFeatureGen(x.copy(), ref, radem, chi, False)
+    out = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(dev(x), out, dev(radem), dev(chi), False)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 4e-7 * np.sqrt(2.0 / rffs)
+
+
+def test_empty_input_raises():
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    radem, chi = orc.draw_sorf_params(64, 10, 3)
+    with pytest.raises(RuntimeError):
+        ext.hipRBFFeatureGen(torch.zeros(0, 10, device=DEV), torch.zeros(0, 64, dtype=torch.float64, device=DEV),
+                             dev(radem), dev(chi), False)
+    with pytest.raises(RuntimeError):
+        ext.hipFastHadamardTransform2D(torch.zeros(0, 16, device=DEV))
+
+
+def test_large_arguments_take_the_double_reduction(oracle):
+    """|chi * x| far beyond 2^18: the reference evaluates glibc cosf/sinf; the device path switches to a
+    double-precision reduction -- still within 4e-7 * scale."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(0)
+    radem, chi = orc.draw_sorf_params(2048, 256, 3)
+    x = (rng.standard_normal((16, 256)) * 3.0e5).astype(np.float32)
+    ref = np.zeros((16, 2048))
+    oracle.cpuRBFFeatureGen(x.copy(), ref, radem, chi, False)
+    out = torch.zeros((16, 2048), dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(dev(x), out, dev(radem), dev(chi), False)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 4e-7 * np.sqrt(1.0 / 1024)
+    v = torch.randn(2048, dtype=torch.float64, device=DEV)
+    w = torch.zeros(2048, dtype=torch.float64, device=DEV)
+    ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), v, w, False)
+    wref = ref.T @ (ref @ v.cpu().numpy())
+    assert np.abs(w.cpu().numpy() - wref).max() <= 1e-5 * np.abs(wref).max()
+
+
+@pytest.mark.parametrize("L,C,cw", [(9, 21, 9), (12, 21, 9), (40, 1, 1), (30, 48, 21), (33, 100, 11)])
+def test_conv_ragged_and_single_kmer(oracle, L, C, cw):
+    """seqlen == conv_width (one k-mer), mixed lengths, graph kernels (conv_width 1), and windows on both
+    sides of the 1024-wide fast path (21*48 = 1008 -> P = 1024; 11*100 = 1100 -> P = 2048)."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(L * C)
+    n, rffs = 6, 1024
+    radem, chi = orc.draw_sorf_params(rffs, cw * C, 5, conv=True)
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = np.array([cw, L, cw, max(cw, L - 1), L, max(cw, L // 2)], np.int32)
+    for sc in (0, 1, 2):
+        ref = np.zeros((n, rffs))
+        oracle.cpuConv1dFGen(x, ref, radem, chi, sl, cw, sc)
+        out = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+        ext.hipConv1dFGen(dev(x), out, dev(radem), dev(chi), sl, cw, sc)
+        kmax = int(sl.max()) - cw + 1
+        assert np.abs(out.cpu().numpy() - ref).max() <= 4e-7 * np.sqrt(2.0 / rffs) * kmax
+    F = rffs // 2
+    P = orc.padded_dims(cw * C)
+    reps = -(-F // P)
+    radem_m = rng.choice(np.asarray([-1, 1], np.int8), size=(3, 1, reps * P))
+    chi_m = np.ascontiguousarray(chi[:F])
+    ref = np.zeros((n, F), np.float32)
+    oracle.cpuConv1dMaxpool(x, ref, radem_m, chi_m, sl, cw)
+    out = torch.zeros((n, F), dtype=torch.float32, device=DEV)
+    ext.hipConv1dMaxpool(dev(x), out, dev(radem_m), dev(chi_m), sl, cw)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_fused_matvec_small_n_and_odd_tiles(oracle):
+    """fewer datapoints than slots, F not a multiple of 1024 (partial last tile), nb = 3 and nb = 5."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(1)
+    for n, d, rffs in [(1, 7, 30), (3, 100, 5000), (17, 64, 6146), (5, 300, 9000), (2, 1024, 16384)]:
+        radem, chi = orc.draw_sorf_params(rffs, d, 4)
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        z = np.zeros((n, rffs))
+        oracle.cpuRBFFeatureGen(x.copy(), z, radem, chi, True)
+        z[:, 0] = 1.0
+        v = rng.standard_normal(rffs)
+        w = torch.zeros(rffs, dtype=torch.float64, device=DEV)
+        ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), dev(v), w, True)
+        ref = z.T @ (z @ v)
+        assert np.abs(w.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), (n, d, rffs)
