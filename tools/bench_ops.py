@@ -32,7 +32,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     for (d, m, name, parms) in [(1024, 8192, "Matern", {"matern_nu": 2.5}), (256, 4096, "RBF", {}),
-                                (512, 16384, "RBF", {})]:
+                                (512, 16384, "RBF", {}), (512, 32768, "RBF", {})]:
         n = args.rows
         x = torch.randn(n, d, device=dev) / np.sqrt(d)
         k = make_kernel(name, (n, d), m, 123, dev, parms)

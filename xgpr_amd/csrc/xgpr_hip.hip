@@ -614,6 +614,8 @@ struct WaveArgs {
     int fit_intercept;
     float nc; float chi_scale; // per-round normaliser (odd log2 P) / folded normaliser^3 (even)
     double scale;
+    double *tpart;            // two-pass matvec: per-(datapoint, tile) partial dots [rows, nb]
+    int add_to_slab;          // two-pass matvec: slabs accumulate over row windows
 };
 
 // ---- cudaRBFFeatureGen: one wave per (datapoint, tile); 4 waves per workgroup.
@@ -790,10 +792,18 @@ __global__ __launch_bounds__(512, 2) void wave_ztz_kernel(WaveArgs a) {
     float *tb = reinterpret_cast<float *>(smem + pv_bytes + 256) + (threadIdx.x >> 6) * (TP ? TBUF_FLOATS : 0);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = w % a.nb;
-    const int g = w / a.nb;
-    const long slot = (long)blockIdx.x * a.G + g;
-    const long nslots = (long)gridDim.x * a.G;
+    int b, g;
+    long slot, nslots;
+    if (MATVEC) {                      // workgroup = G slots x nb tiles, coupled through LDS
+        b = w % a.nb; g = w / a.nb;
+        slot = (long)blockIdx.x * a.G + g;
+        nslots = (long)gridDim.x * a.G;
+    } else {                           // independent waves: flat (slot, tile) numbering over the grid
+        const long gw = (long)blockIdx.x * (blockDim.x >> 6) + w;
+        b = __builtin_amdgcn_readfirstlane((int)(gw % a.nb)); g = 0;
+        slot = gw / a.nb;
+        nslots = ((long)gridDim.x * (blockDim.x >> 6)) / a.nb;
+    }
     const long iters = (a.n + nslots - 1) / nslots;
     const long f0 = (long)b * 1024 + lane;
     cmask_t mk = as_cmask(a.masks + (long)b * 16);
@@ -859,6 +869,11 @@ __global__ __launch_bounds__(512, 2) void wave_ztz_kernel(WaveArgs a) {
             double t = 0.0;
             for (int bb = 0; bb < a.nb; bb++) t += part[(it & 1) * 16 + g * a.nb + bb];
             u = t * s2;
+        } else if (a.tpart) {          // second pass of the two-pass matvec: t = sum of the tile partials
+            double t = 0.0;
+            if (active)
+                for (int bb = 0; bb < a.nb; bb++) t += a.tpart[row * a.nb + bb];
+            u = t * s2;
         } else {
             u = active ? a.vec[row] * a.scale : 0.0;   // y[row] * scale
         }
@@ -876,7 +891,63 @@ __global__ __launch_bounds__(512, 2) void wave_ztz_kernel(WaveArgs a) {
     #pragma unroll
     for (int r = 0; r < 16; r++) {
         const long f = f0 + r * 64;
-        if (f < a.F) *reinterpret_cast<double2 *>(slab + 2 * f) = make_double2(ac[r], as[r]);
+        if (f < a.F) {
+            double2 *o = reinterpret_cast<double2 *>(slab + 2 * f);
+            double2 val = make_double2(ac[r], as[r]);
+            if (a.add_to_slab) { const double2 old = *o; val.x += old.x; val.y += old.y; }
+            *o = val;
+        }
+    }
+}
+
+// ---- first pass of the two-pass matvec (num_freqs > 8192, where one workgroup cannot hold a
+// datapoint's tiles): independent waves, tile b fixed per wave with its slice of v in registers;
+// tpart[row, b] = partial dot of tile b of datapoint `row` with v (unscaled cos/sin, as in the
+// fused kernel).  The second pass is wave_ztz_kernel<.., false, ..> with a.tpart set.
+template <int LOG2P, bool TPREQ>
+__global__ __launch_bounds__(256) void wave_dot_kernel(WaveArgs a) {
+    constexpr bool TP = TPREQ && LOG2P >= 7;
+    __shared__ __attribute__((aligned(16))) float tbuf[TP ? 4 * TBUF_FLOATS : 4];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long gw = (long)blockIdx.x * 4 + w;
+    const int b = __builtin_amdgcn_readfirstlane((int)(gw % a.nb));
+    const long slot = gw / a.nb;
+    const long nslots = ((long)gridDim.x * 4) / a.nb;
+    const long f0 = (long)b * 1024 + lane;
+    cmask_t mk = as_cmask(a.masks + (long)b * 16);
+    float *tb = tbuf + w * (TP ? TBUF_FLOATS : 1);
+    uint32_t sw[3] = {0, 0, 0};
+    if constexpr (TP) load_sign_words(sw, a.masks, a.MW, b, lane);
+    float ch[16];
+    double pc[16], ps[16];
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long f = f0 + r * 64;
+        const bool ok = f < a.F;
+        ch[r] = ok ? a.chi[f] * a.chi_scale : 0.0f;
+        double2 p = ok ? *reinterpret_cast<const double2 *>(a.vec + 2 * f) : make_double2(0.0, 0.0);
+        pc[r] = p.x; ps[r] = p.y;
+    }
+    const bool icpt = a.fit_intercept && b == 0 && lane == 0;
+    const double inv_scale = 1.0 / a.scale;
+    for (long row = slot; row < a.n; row += nslots) {
+        float v[16], cs[16], sn[16];
+        if constexpr (!TP) mk = launder(mk);
+        wave_load<LOG2P>(v, a.x + row * a.row_stride, a.d, lane);
+        tile_sorf<LOG2P, TP>(v, mk, sw, tb, a.MW, a.nc, lane);
+        #pragma unroll
+        for (int r = 0; r < 16; r++) v[r] *= ch[r];
+        tile_sincos(v, sn, cs);
+        const double c0 = icpt ? inv_scale : (double)cs[0];
+        double u0 = __builtin_fma(c0, pc[0], 0.0), u1 = __builtin_fma((double)sn[0], ps[0], 0.0);
+        #pragma unroll
+        for (int r = 1; r < 16; r++) {
+            u0 = __builtin_fma((double)cs[r], pc[r], u0);
+            u1 = __builtin_fma((double)sn[r], ps[r], u1);
+        }
+        const double u = wave_sum(u0 + u1);
+        if (lane == 0) a.tpart[row * a.nb + b] = u;
     }
 }
 
@@ -1279,6 +1350,29 @@ int conv_impl(const T *x, double *out, double *grad, float *outf, const int8_t *
 }
 
 constexpr long ZTZ_MAX_SLABS = 2048;
+constexpr long ZTZ_ROW_WINDOW = 65536;     // two-pass matvec: rows per (dot, update) launch pair
+
+size_t ztz_workspace_bytes(long num_rffs, long R) {
+    size_t b = masks_bytes(R) + (size_t)ZTZ_MAX_SLABS * num_rffs * sizeof(double);
+    if (num_rffs / 2 > 8192) b += (size_t)ZTZ_ROW_WINDOW * ((num_rffs / 2 + 1023) / 1024) * sizeof(double);
+    return b;
+}
+
+// independent-wave kernels: 4 waves per workgroup, two waves per SIMD over the chip, a whole number
+// of datapoint slots (nb waves each), at most ZTZ_MAX_SLABS slots and no more slots than datapoints
+void flat_geometry(int nb, long n, int &waves_per_wg, long &nblocks, long &nslots) {
+    waves_per_wg = 4;
+    long waves = (long)device_cus() * 8;
+    nslots = waves / nb > 0 ? waves / nb : 1;
+    if (nslots > ZTZ_MAX_SLABS) nslots = ZTZ_MAX_SLABS;
+    if (nslots > n) nslots = n;
+    // nslots * nb must be a multiple of 4
+    while ((nslots * nb) % 4 != 0) nslots++;
+    nblocks = nslots * nb / 4;
+}
+
+int ztz_two_pass(const float *x, const int8_t *radem, const float *chi, const double *vec, double *w_out, long n,
+                 long d, long num_rffs, long num_freqs, long R, int fit_intercept, void *workspace, hipStream_t st);
 
 template <bool MATVEC>
 int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double *vec, double *w_out, long n,
@@ -1290,13 +1384,15 @@ int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double
     if (2 * num_freqs != num_rffs || num_freqs > R) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
     if (R % P != 0) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
     if (P > 1024) return fail(XGPR_ERR_UNSUPPORTED, "fused matvec supports padded width <= 1024");
-    if (num_freqs > 8192) return fail(XGPR_ERR_UNSUPPORTED, "fused matvec supports num_freqs <= 8192");
+    if (num_freqs > 65536) return fail(XGPR_ERR_UNSUPPORTED, "fused matvec supports num_freqs <= 65536");
     if ((MATVEC && !aligned16(vec)) || !aligned16(w_out)) return fail(XGPR_ERR_WORKSPACE, "vector pointers must be 16-byte aligned");
     const size_t mb = masks_bytes(R);
-    const size_t need = mb + (size_t)ZTZ_MAX_SLABS * num_rffs * sizeof(double);
+    const size_t need = ztz_workspace_bytes(num_rffs, R);
     if (!workspace || wbytes < need || !aligned16(workspace))
         return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_ztz_matvec_workspace_bytes)");
     hipStream_t st = (hipStream_t)stream;
+    if (MATVEC && num_freqs > 8192)
+        return ztz_two_pass(x, radem, chi, vec, w_out, n, d, num_rffs, num_freqs, R, fit_intercept, workspace, st);
 
     WaveArgs a = {};
     a.x = x; a.masks = (const uint64_t *)workspace; a.chi = chi; a.vec = vec;
@@ -1314,13 +1410,19 @@ int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double
     int rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
     if (rc) return rc;
 
-    const int waves_per_wg = a.nb * a.G;
-    const int wg_per_cu = 8 / waves_per_wg > 0 ? 8 / waves_per_wg : 1;     // 2 waves per SIMD
+    int waves_per_wg = a.nb * a.G;
+    int wg_per_cu = 8 / waves_per_wg > 0 ? 8 / waves_per_wg : 1;     // 2 waves per SIMD
     long nblocks = (long)device_cus() * wg_per_cu;
-    const long max_by_rows = (n + a.G - 1) / a.G;
-    if (nblocks > max_by_rows) nblocks = max_by_rows;
-    if (nblocks * a.G > ZTZ_MAX_SLABS) nblocks = ZTZ_MAX_SLABS / a.G;
-    const long nslabs = nblocks * a.G;
+    long nslabs;
+    if (MATVEC) {
+        const long max_by_rows = (n + a.G - 1) / a.G;
+        if (nblocks > max_by_rows) nblocks = max_by_rows;
+        if (nblocks * a.G > ZTZ_MAX_SLABS) nblocks = ZTZ_MAX_SLABS / a.G;
+        nslabs = nblocks * a.G;
+    } else {
+        flat_geometry(a.nb, n, waves_per_wg, nblocks, nslabs);
+        wg_per_cu = 2;
+    }
     const size_t lds_base = (MATVEC ? (size_t)a.nb * 1024 * 16 : 0) + 256;
     const size_t lds_t = lds_base + (size_t)waves_per_wg * TBUF_FLOATS * sizeof(float);
     // the two-layout FHT needs 5 KiB of LDS per wave; without room for it (M = 16384) the register-only FHT runs
@@ -1343,6 +1445,58 @@ int ztz_impl(const float *x, const int8_t *radem, const float *chi, const double
     HIP_TRY(hipGetLastError(), "wave_ztz_kernel launch");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((num_rffs + 63) / 64)), dim3(256), 0, st, a.wpart, w_out,
                        num_rffs, nslabs);
+    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    return 0;
+}
+
+// Z^T(Z v) for num_freqs > 8192: per window of rows, (1) wave_dot_kernel writes the per-tile partial
+// dots, (2) the update kernel recomputes the features and accumulates z_i * (z_i . v) into its slabs;
+// then the slabs are reduced as in the single-pass path.  Costs one extra SORF + sincos per feature
+// but has no coupling between the tiles of a datapoint, so it works for any number of tiles.
+int ztz_two_pass(const float *x, const int8_t *radem, const float *chi, const double *vec, double *w_out, long n,
+                 long d, long num_rffs, long num_freqs, long R, int fit_intercept, void *workspace, hipStream_t st) {
+    const long P = padded_width(d);
+    const size_t mb = masks_bytes(R);
+    WaveArgs a = {};
+    a.masks = (const uint64_t *)workspace; a.chi = chi; a.vec = vec;
+    a.wpart = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(workspace) + mb);
+    a.tpart = a.wpart + (size_t)ZTZ_MAX_SLABS * num_rffs;
+    a.row_stride = d; a.F = num_freqs; a.d = (int)d;
+    a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
+    a.G = 1; a.fit_intercept = fit_intercept;
+    a.scale = rbf_scale<float>(num_freqs, fit_intercept);
+    const int lg = ilog2(P);
+    fill_norms(a, lg);
+    int rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
+    if (rc) return rc;
+    long nslabs_max = 0;
+    for (long row0 = 0; row0 < n; row0 += ZTZ_ROW_WINDOW) {
+        const long rows = n - row0 < ZTZ_ROW_WINDOW ? n - row0 : ZTZ_ROW_WINDOW;
+        a.x = x + row0 * d;
+        a.n = rows;
+        a.add_to_slab = row0 > 0;
+        int wpw; long nblocks, nslots;
+        flat_geometry(a.nb, row0 == 0 ? rows : ZTZ_ROW_WINDOW, wpw, nblocks, nslots);
+        if (row0 == 0) nslabs_max = nslots;
+        // later (shorter) windows keep the first window's slot count so that every slab is revisited
+        if (row0 > 0) { nslots = nslabs_max; nblocks = nslots * a.nb / 4; }
+        const bool tp = lg >= 7;
+#define CALL_DOT(LG)                                                                                          \
+        if (tp) hipLaunchKernelGGL((wave_dot_kernel<LG, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((wave_dot_kernel<LG, false>), dim3((unsigned)nblocks), dim3(256), 0, st, a);
+        DISPATCH_LOG2P(lg, CALL_DOT)
+#undef CALL_DOT
+        HIP_TRY(hipGetLastError(), "wave_dot_kernel launch");
+        const size_t lds = 256 + (tp ? (size_t)4 * TBUF_FLOATS * sizeof(float) : 0);
+#define CALL_UPD(LG)                                                                                          \
+        if (tp) hipLaunchKernelGGL((wave_ztz_kernel<LG, false, true>), dim3((unsigned)nblocks), dim3(256), lds, st, a);  \
+        else hipLaunchKernelGGL((wave_ztz_kernel<LG, false, false>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
+        DISPATCH_LOG2P(lg, CALL_UPD)
+#undef CALL_UPD
+        HIP_TRY(hipGetLastError(), "wave_ztz_kernel (update pass) launch");
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((num_rffs + 63) / 64)), dim3(256), 0, st, a.wpart, w_out,
+                       num_rffs, nslabs_max);
     HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
     return 0;
 }
@@ -1453,7 +1607,7 @@ int xgpr_conv1d_maxpool_f64(const double *x, float *out, const int8_t *radem, co
 }
 
 size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2) {
-    return masks_bytes(radem_shape2) + (size_t)ZTZ_MAX_SLABS * num_rffs * sizeof(double);
+    return ztz_workspace_bytes(num_rffs, radem_shape2);
 }
 int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v, double *w_out,
                         long n, long d, long num_rffs, long num_freqs, long radem_shape2, int fit_intercept,

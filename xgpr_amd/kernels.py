@@ -127,8 +127,9 @@ class SORFKernel(KernelBase):
         ext.hipZtY(x_scaled, self.radem_diag, self.chi_arr, y, out, self.fit_intercept, workspace)
 
     def fused_ok(self):
-        """The fused kernels cover padded width <= 1024 and num_freqs <= 8192."""
-        return padded_dims(self._xdim[-1]) <= 1024 and self.num_freqs <= 8192
+        """The fused kernels cover padded width <= 1024 (single pass up to num_freqs = 8192, the
+        two-pass form beyond, up to 65536)."""
+        return padded_dims(self._xdim[-1]) <= 1024 and self.num_freqs <= 65536
 
     def workspace_bytes(self):
         return ext.ztz_workspace_bytes(self.num_rffs, self.radem_diag.shape[2])
