@@ -361,6 +361,27 @@ def g8_e2e(xgpr):
          ratio=np.float64(ratio), preds=preds, zty=pre.get_zty(), yty=np.float64(pre.get_yty()))
 
 
+# ---------------------------------------------------------------- G9: exact fit + variance (next rows)
+def g9_exact(xgpr):
+    """mode="exact" on the reference fixture (tests/fitting_tests/test_exact_fit.py:29-37 settings:
+    RBF, 512 RFFs here to keep the file small): weights, the variance matrix (variance_rffs = 12),
+    predictions.  fitting_toolkit/exact_fitting_toolkit.py:16-72."""
+    from xGPR import xGPRegression
+    from xGPR.data_handling.dataset_builder import build_regression_dataset
+    xtr = np.load(os.path.join(REF_TESTDATA, "0_block_trainxvalues.npy"))
+    ytr = np.load(os.path.join(REF_TESTDATA, "0_block_trainyvalues.npy"))
+    xte = np.load(os.path.join(REF_TESTDATA, "4_block_testxvalues.npy"))[:32]
+    ds = build_regression_dataset(xtr, ytr, chunk_size=2000)
+    hparam = np.array([np.log(np.sqrt(0.0767)), np.log(0.358)])
+    mod = xGPRegression(num_rffs=512, kernel_choice="RBF", variance_rffs=12, random_seed=123,
+                        device="cpu", kernel_settings={"intercept": True})
+    mod.set_hyperparams(hparam, ds)
+    mod.fit(ds, mode="exact")
+    preds, var = mod.predict(xte, get_var=True)
+    save("g9_exact.npz", hparam_log=hparam, weights=np.asarray(mod.weights), var=np.asarray(mod.var),
+         xtest=xte, preds=preds, pred_var=var)
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -371,3 +392,4 @@ if __name__ == "__main__":
     g6_draws(xgpr)
     g7_cg(xgpr)
     g8_e2e(xgpr)
+    g9_exact(xgpr)

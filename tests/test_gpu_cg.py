@@ -151,3 +151,50 @@ def test_precond_apply_and_fused_cg_steps():
         beta = ((r - alpha * w2) * znext).sum() / rz
         assert rel(pn, znext + beta * p) < 1e-12
         assert np.isclose(scal.cpu().numpy()[3], beta, rtol=1e-10)
+
+
+def test_g9_exact_fit_and_variance():
+    """mode="exact" (reference fitting_toolkit/exact_fitting_toolkit.py:16-72) on the reference
+    fixture: weights, variance matrix and predictions against the reference's own run."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.exact import calc_weights_exact, calc_variance_exact, predict_mean
+    g8, g9 = load_golden("g8_e2e.npz"), load_golden("g9_exact.npz")
+    x, y = g8["xtrain"], g8["ytrain"]
+    ds = build_regression_dataset(x, y, chunk_size=2000, device=DEV)
+    kern = make_kernel("RBF", x.shape, 512, 123, DEV, {"intercept": True})
+    kern.set_hyperparams(g9["hparam_log"], logspace=True)
+    w, _, _ = calc_weights_exact(ds, kern)
+    assert rel(w, g9["weights"]) < 1e-5
+    var = calc_variance_exact(kern, ds, 12)
+    assert rel(var, g9["var"]) < 1e-5
+    preds = predict_mean(kern, w, torch.from_numpy(g9["xtest"]).to(DEV), ds.get_ymean(), ds.get_ystd())
+    assert np.allclose(preds.cpu().numpy(), g9["preds"], rtol=1e-5, atol=1e-6)
+
+
+def test_batched_rhs_cg_matches_oracle(oracle):
+    """k > 1 right-hand sides (the shape of the reference's NMLL probes, cg_tools.py:203-302 with
+    resid [M, 2, k]): chunked block-GEMM matvec on the device vs the oracle's batched CG."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import ConjugateGrad
+    rng = np.random.default_rng(8)
+    n, d, m, k = 1500, 20, 256, 5
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    y = rng.standard_normal(n)
+    hp = np.array([0.4, 0.9])
+    rhs = rng.standard_normal((m, k))
+    ds = build_regression_dataset(x, y, chunk_size=400, device=DEV)
+    kern = make_kernel("RBF", x.shape, m, 123, DEV, {})
+    kern.set_hyperparams(hp, logspace=False)
+    resid = torch.zeros((m, 2, k), dtype=torch.float64, device=DEV)
+    resid[:, 0, :] = torch.from_numpy(rhs).to(DEV)
+    xk, conv, niter, losses = ConjugateGrad().fit(ds, kern, None, resid, 300, 1e-9, False)
+    ods = orc.OracleDataset(x.astype(np.float64), y, chunk_size=400)
+    okern = orc.OracleKernel("RBF", m, x.shape, hp, 123, ops=oracle)
+    oresid = np.zeros((m, 2, k))
+    oresid[:, 0, :] = rhs
+    xref, oconv, oniter, _ = orc.cg_fit(ods, okern, None, oresid, 300, 1e-9)
+    assert conv and oconv and abs(niter - oniter) <= 1
+    assert rel(xk, xref) < 1e-6

@@ -50,15 +50,14 @@ class ConjugateGrad:
     def _matvec(self, dataset, kernel, vec, matvec):
         """cg_tools.py:173-200 (regression branch): matvec <- (Z^T Z + lambda^2) vec."""
         matvec.zero_()
-        if kernel.fused_ok():
+        # k <= 2 right-hand sides: one fused pass per column (Z never written).  More columns (the
+        # NMLL probes, k = 26): generate each chunk of Z once and let the two block GEMMs
+        # [n x M][M x k], [M x n][n x k] run on the matrix cores (library float64 MFMA GEMM).
+        if kernel.fused_ok() and vec.shape[1] <= 2:
             xs = dataset.scaled_x(kernel.hyperparams[1])
             if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != xs.device:
                 self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=xs.device)
-            if vec.shape[1] == 1:
-                kernel.ztz_matvec(xs, vec[:, 0].contiguous(), matvec[:, 0], self._ws) \
-                    if matvec[:, 0].is_contiguous() else self._matvec_cols(kernel, xs, vec, matvec)
-            else:
-                self._matvec_cols(kernel, xs, vec, matvec)
+            self._matvec_cols(kernel, xs, vec, matvec)
         else:
             for x, lengths in dataset.get_chunked_x_data():
                 z = kernel.transform_x(x, lengths)

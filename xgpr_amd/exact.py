@@ -1,0 +1,74 @@
+"""Closed-form pieces that share the path's dense accumulations ("next" rows of SURVEY.md section 8f):
+the design matrix Z^T Z (the same float64 MFMA block-GEMM as the preconditioner accumulate, with
+rank -> M), exact weights, the variance matrix and the predictive mean.
+
+  * ``calc_design_mat``     <-> scoring_toolkit/exact_nmll_calcs.py:42-78
+  * ``direct_weight_calc``  <-> scoring_toolkit/exact_nmll_calcs.py:80-110
+  * ``calc_weights_exact``  <-> fitting_toolkit/exact_fitting_toolkit.py:16-40
+  * ``calc_variance_exact`` <-> fitting_toolkit/exact_fitting_toolkit.py:43-72, exact_nmll_calcs.py:116-139
+  * ``predict_mean``        <-> xgp_regression.py:77-145 (mean only)
+
+Feature generation is the HIP operator; the M x M contractions and factorizations are library
+calls (rocBLAS / rocSOLVER through torch).  Partial sums are all-reduced over ranks.
+"""
+import torch
+
+
+def calc_design_mat(dataset, kernel):
+    comm = dataset.comm
+    m = kernel.get_num_rffs()
+    z_trans_z = torch.zeros((m, m), dtype=torch.float64, device=kernel.device)
+    z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
+    y_trans_y = torch.zeros(1, dtype=torch.float64, device=kernel.device)
+    for xin, yin, ldata in dataset.get_chunked_data():
+        xfeatures, ydata = kernel.transform_x_y(xin, yin, ldata)
+        z_trans_y += xfeatures.T @ ydata
+        z_trans_z += xfeatures.T @ xfeatures
+        y_trans_y += ydata @ ydata
+    comm.all_reduce_(z_trans_z)
+    comm.all_reduce_(z_trans_y)
+    comm.all_reduce_(y_trans_y)
+    return z_trans_z, z_trans_y, float(y_trans_y.item())
+
+
+def direct_weight_calc(chol_z_trans_z, z_trans_y, kernel):
+    """exact_nmll_calcs.py:80-110 -- adds lambda^2 to the diagonal (in place), factorizes, solves."""
+    lambda_p = kernel.get_hyperparams(logspace=False)[0]
+    chol_z_trans_z.diagonal().add_(float(lambda_p) ** 2)
+    chol = torch.linalg.cholesky(chol_z_trans_z)
+    weights = torch.cholesky_solve(z_trans_y[:, None], chol)[:, 0]
+    return chol, weights
+
+
+def calc_weights_exact(dataset, kernel):
+    """exact_fitting_toolkit.py:16-40.  Faithful to the reference, lambda^2 reaches the diagonal
+    TWICE here (once in this function, :36, and again inside direct_weight_calc,
+    exact_nmll_calcs.py:100-101): the exact-mode weights solve (Z^T Z + 2 lambda^2) w = Z^T y."""
+    z_trans_z, z_trans_y, _ = calc_design_mat(dataset, kernel)
+    lambda_p = kernel.get_hyperparams(logspace=False)[0]
+    z_trans_z.diagonal().add_(float(lambda_p) ** 2)
+    _, weights = direct_weight_calc(z_trans_z, z_trans_y, kernel)
+    return weights, 1, []
+
+
+def calc_variance_exact(kernel, dataset, variance_rffs):
+    """exact_fitting_toolkit.py:43-72: pinv of the leading variance_rffs x variance_rffs block of
+    Z^T Z + lambda^2."""
+    comm = dataset.comm
+    z_trans_z = torch.zeros((variance_rffs, variance_rffs), dtype=torch.float64, device=kernel.device)
+    for xdata, ldata in dataset.get_chunked_x_data():
+        xfeatures = kernel.transform_x(xdata, ldata)
+        z_trans_z += xfeatures[:, :variance_rffs].T @ xfeatures[:, :variance_rffs]
+    comm.all_reduce_(z_trans_z)
+    z_trans_z.diagonal().add_(float(kernel.get_lambda()) ** 2)
+    return torch.linalg.pinv(z_trans_z)
+
+
+def predict_mean(kernel, weights, input_x, trainy_mean, trainy_std, sequence_lengths=None, chunk_size=2000):
+    """xgp_regression.py:77-145, mean only: per chunk ``(Z * w).sum(1)``, then un-standardise."""
+    preds = []
+    for i in range(0, input_x.shape[0], chunk_size):
+        sl = None if sequence_lengths is None else sequence_lengths[i:i + chunk_size]
+        z = kernel.transform_x(input_x[i:i + chunk_size], sl)
+        preds.append((z * weights[None, :]).sum(dim=1))
+    return torch.cat(preds) * trainy_std + trainy_mean
