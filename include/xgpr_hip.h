@@ -187,6 +187,21 @@ int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefac
                            double *z, long M, long rank, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* ---- resident feature cache (an MI355X-side option, no reference counterpart: the reference
+ * regenerates Z chunk by chunk on every CG iteration because it cannot hold it).
+ * xgpr_rbf_feature_cache_f32 is cudaRBFFeatureGen (xgpr_cuda_rfgen_cpp_ext.cpp:32-40) writing the
+ * float32 (cos, sin) pairs *before* scaling into zc[n, num_rffs] -- exactly the values whose
+ * widening times the scale is the float64 output -- so a shard's Z stays in HBM (32 KB per
+ * datapoint at 8192 features).  xgpr_zcache_matvec_f32 is then the chunk body of the CG matvec
+ * (fitting_toolkit/cg_tools.py:189-191) streamed from that cache at HBM speed:
+ * w_out = sum_i z_i (z_i . v), z_i = scale * zc[i] with Z[:,0] = 1 under fit_intercept; float64
+ * accumulation, deterministic.  num_freqs <= 8192; workspace as for xgpr_ztz_matvec_f32. */
+int xgpr_rbf_feature_cache_f32(const float *x, float *zc, const int8_t *radem, const float *chi,
+                               long n, long d, long num_rffs, long num_freqs, long radem_shape2,
+                               void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_zcache_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs,
+                           int fit_intercept, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- self test of the cross-lane butterfly stages the wave-level FHT is built on: for each
  * of the 6 lane strides h = 1, 2, 4, 8, 16, 32 runs one stage on v[r] = lane + 64 r
  * (r = 0..15) and writes the result to out[6][16][64] (int32, device).  Expected:

@@ -198,3 +198,23 @@ def test_batched_rhs_cg_matches_oracle(oracle):
     xref, oconv, oniter, _ = orc.cg_fit(ods, okern, None, oresid, 300, 1e-9)
     assert conv and oconv and abs(niter - oniter) <= 1
     assert rel(xk, xref) < 1e-6
+
+
+def test_cg_with_resident_feature_cache_matches_regenerating_cg():
+    """cache_features=True (Z kept in HBM as float32, streamed each iteration) gives the same solve as
+    the default (features regenerated each iteration): same iteration count, weights to 1e-8."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import cg_fit_lib_internal
+    g = load_golden("g7_cg.npz")
+    x, y = g["x"], g["y"]
+    ds = build_regression_dataset(x, y, chunk_size=500, device=DEV)
+    kern = make_kernel("Matern", x.shape, int(g["num_rffs"]), 123, DEV, {"matern_nu": 2.5})
+    kern.set_hyperparams(g["hyperparams"], logspace=False)
+    pre = RandNysPreconditioner(kern, ds, 64, False, 123, "srht")
+    w0, n0, _ = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False)
+    w1, n1, _ = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False, cache_features=True)
+    assert n0 == n1 == int(g["Matern_srht_niter"])
+    assert rel(w1, w0.cpu().numpy()) < 1e-8      # float64 summation order differs between the two kernels
+    assert rel(w1, g["Matern_srht_weights"]) < 1e-5

@@ -271,3 +271,36 @@ def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     ext.hipZtY(dev(x), dev(radem), dev(chi), dev(y), zty, icpt)
     refy = z.T @ y
     assert np.abs(zty.cpu().numpy() - refy).max() <= 1e-6 * np.abs(refy).max()
+
+
+@pytest.mark.parametrize("d,rffs,icpt,n", [(32, 512, True, 2000), (20, 64, False, 100), (256, 4096, True, 3000),
+                                           (100, 3000, True, 777), (1024, 8192, True, 1500), (512, 16384, False, 300),
+                                           (7, 10, True, 33), (64, 6146, True, 5), (3, 2, False, 1)])
+def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
+    """The resident float32 feature cache holds exactly the float32 cos/sin the float64 operator
+    widens (bit-for-bit: cache * scale == hipRBFFeatureGen output), and the matvec streamed from it
+    equals Z.T @ (Z @ v) from the oracle's features."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(d + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, d, 11)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    zc = torch.empty((n, rffs), dtype=torch.float32, device=DEV)
+    ext.hipRBFFeatureCache(dev(x), zc, dev(radem), dev(chi))
+    zf = torch.empty((n, rffs), dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(dev(x), zf, dev(radem), dev(chi), icpt)
+    F = rffs // 2
+    scale = float(np.float32(np.sqrt(1.0 / (F - 0.5 if icpt else F))))
+    assert torch.equal(zc.double() * scale, zf)
+    z = np.zeros((n, rffs))
+    oracle.cpuRBFFeatureGen(x.copy(), z, radem, chi, icpt)
+    if icpt:
+        z[:, 0] = 1.0
+    v = rng.standard_normal(rffs)
+    ref = z.T @ (z @ v)
+    out = torch.zeros(rffs, dtype=torch.float64, device=DEV)
+    ws = torch.empty(ext.ztz_workspace_bytes(rffs, radem.shape[2]), dtype=torch.uint8, device=DEV)
+    ext.hipZCacheMatvec(zc, dev(v), out, icpt, ws)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    out2 = torch.zeros_like(out)
+    ext.hipZCacheMatvec(zc, dev(v), out2, icpt, ws)
+    assert torch.equal(out, out2)

@@ -42,6 +42,19 @@ def main():
         ms = timeit(lambda: k.ztz_matvec(x, v, out, ws))
         print(f"fused ZtZ matvec  d={d:5d} M={m:6d} n={n}: {ms:8.3f} ms  {n / ms / 1e3:8.1f} Mrows/s  "
               f"{n * m / ms / 1e6:8.1f} Gfeat/s  X-read {4 * d * n / ms / 1e6:7.1f} GB/s")
+        if k.cache_ok():
+            zc = k.build_feature_cache(x)
+            ms = timeit(lambda: k.build_feature_cache(x), reps=2, warm=0)
+            print(f"feature cache     d={d:5d} M={m:6d} n={n}: {ms:8.3f} ms  {n / ms / 1e3:8.1f} Mrows/s  "
+                  f"HBM {(4 * d + 4 * m) * n / ms / 1e6:7.1f} GB/s")
+            ms = timeit(lambda: k.ztz_matvec_cached(zc, v, out, ws))
+            print(f"cached ZtZ matvec d={d:5d} M={m:6d} n={n}: {ms:8.3f} ms  {n / ms / 1e3:8.1f} Mrows/s  "
+                  f"HBM {4 * m * n / ms / 1e6:7.1f} GB/s")
+            o2 = torch.zeros_like(out)
+            k.ztz_matvec(x, v, o2, ws)
+            k.ztz_matvec_cached(zc, v, out, ws)
+            print(f"   cached vs fused max rel diff {float((out - o2).abs().max() / o2.abs().max()):.2e}")
+            del zc
         fr = min(n, (1 << 30) // (8 * m))
         z = torch.empty(fr, m, dtype=torch.float64, device=dev)
         ms = timeit(lambda: ext.hipRBFFeatureGen(x[:fr], z, k.radem_diag, k.chi_arr, True))

@@ -37,6 +37,8 @@ SIGNATURES = {
     "xgpr_precond_scale_f64": [_vp, _vp, _d, _l, _vp],
     "xgpr_cg_step2_f64": [_vp, _vp, _vp, _vp, _vp, _l, _vp],
     "xgpr_precond_apply_f64": [_vp, _vp, _d, _vp, _vp, _l, _l, _vp, _sz, _vp],
+    "xgpr_rbf_feature_cache_f32": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _vp, _sz, _vp],
+    "xgpr_zcache_matvec_f32": [_vp, _vp, _vp, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
 }
 SIZE_FUNCS = {

@@ -618,8 +618,10 @@ struct WaveArgs {
     int add_to_slab;          // two-pass matvec: slabs accumulate over row windows
 };
 
-// ---- cudaRBFFeatureGen: one wave per (datapoint, tile); 4 waves per workgroup.
-template <int LOG2P>
+// ---- cudaRBFFeatureGen: one wave per (datapoint, tile); 4 waves per workgroup.  With CACHE the
+// kernel writes the float32 (cos, sin) pairs before scaling -- the exact values the float64
+// output is the widening of -- into a.outf [n, 2F] (the resident feature cache).
+template <int LOG2P, bool CACHE>
 __global__ __launch_bounds__(256) void wave_rbf_kernel(WaveArgs a) {
     const int lane = threadIdx.x & 63;
     const long item = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (long)blockIdx.x * 4;
@@ -644,6 +646,15 @@ __global__ __launch_bounds__(256) void wave_rbf_kernel(WaveArgs a) {
         arg[r] = v[r] * (ch * a.chi_scale);
     }
     tile_sincos(arg, sn, cs);
+    if constexpr (CACHE) {
+        float *crow = a.outf + i * 2 * a.F;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long f = f0 + r * 64;
+            if (full || f < a.F) *reinterpret_cast<float2 *>(crow + 2 * f) = make_float2(cs[r], sn[r]);
+        }
+        return;
+    }
     double *orow = a.out + i * 2 * a.F;
     if (full) {
         #pragma unroll
@@ -948,6 +959,111 @@ __global__ __launch_bounds__(256) void wave_dot_kernel(WaveArgs a) {
         }
         const double u = wave_sum(u0 + u1);
         if (lane == 0) a.tpart[row * a.nb + b] = u;
+    }
+}
+
+// ---- CG matvec over a resident float32 feature cache: w = sum_i z_i (z_i . v) with z_i read from
+// HBM instead of regenerated.  288 GB of HBM hold the cache of a whole shard (32 KB per datapoint at
+// M = 8192), and streaming it is faster than regenerating the features on the vector pipe.  Same
+// ownership as wave_ztz_kernel (wave b of a datapoint slot owns tile b, float64 accumulators in
+// registers, v in LDS, one barrier per datapoint, slabs reduced in order).  The kernel is bound by
+// bytes in flight (HBM latency under load is several microseconds), so every wave keeps a ring of
+// RING datapoints in registers: RING - 1 of them loading while one is consumed.  The lane <->
+// frequency map is chosen for 16-byte loads: lane l, load q holds frequencies
+// f = 1024 b + 128 q + 2 l and f + 1 as (cos, sin, cos, sin).
+struct ZcArgs {
+    const float *zc; const double *vec; double *wpart;
+    long n; long F; int nb; int G; int fit_intercept; double scale;
+};
+
+template <bool VEC4, int RING>
+__global__ __launch_bounds__(512, 2) void zcache_ztz_kernel(ZcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *pv = reinterpret_cast<double2 *>(smem);                              // [nb * 1024] (cos, sin) of v
+    double *part = reinterpret_cast<double *>(smem + (size_t)a.nb * 1024 * 16);   // [2][G][8], zero padded
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = w % a.nb, g = w / a.nb;
+    const long slot = (long)blockIdx.x * a.G + g;
+    const long nslots = (long)gridDim.x * a.G;
+    const long iters = (a.n + nslots - 1) / nslots;
+    for (long f = threadIdx.x; f < (long)a.nb * 1024; f += blockDim.x)
+        pv[f] = f < a.F ? *reinterpret_cast<const double2 *>(a.vec + 2 * f) : make_double2(0.0, 0.0);
+    if (threadIdx.x < 2 * 8 * 8) part[threadIdx.x] = 0.0;
+    __syncthreads();
+    const long fb = (long)b * 1024 + 2 * lane;           // first frequency of load q is fb + 128 q
+    double ac[32];
+    #pragma unroll
+    for (int j = 0; j < 32; j++) ac[j] = 0.0;
+    const bool icpt = a.fit_intercept && b == 0 && lane == 0;
+    const double inv_scale = 1.0 / a.scale;
+    const double s2 = a.scale * a.scale;
+
+    auto load_row = [&](long row, float4 (&dst)[8]) {
+        const float *zr = a.zc + row * 2 * a.F;
+        #pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const long f = fb + 128 * q;
+            if (VEC4) {
+                dst[q] = f + 1 < a.F ? *reinterpret_cast<const float4 *>(zr + 2 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float2 lo = f < a.F ? *reinterpret_cast<const float2 *>(zr + 2 * f) : make_float2(0.f, 0.f);
+                float2 hi = f + 1 < a.F ? *reinterpret_cast<const float2 *>(zr + 2 * f + 2) : make_float2(0.f, 0.f);
+                dst[q] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    };
+    float4 buf[RING][8];
+    #pragma unroll
+    for (int k = 0; k < RING; k++) {
+        #pragma unroll
+        for (int q = 0; q < 8; q++) buf[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k * nslots + slot < a.n) load_row(k * nslots + slot, buf[k]);
+    }
+    for (long it0 = 0; it0 < iters; it0 += RING) {
+        #pragma unroll
+        for (int k = 0; k < RING; k++) {
+            const long it = it0 + k;
+            if (it >= iters) break;                      // uniform over the workgroup
+            const long row = it * nslots + slot;
+            const bool active = row < a.n;
+            double u0 = 0.0, u1 = 0.0;
+            #pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const double2 p0 = pv[fb + 128 * q], p1 = pv[fb + 128 * q + 1];
+                const double c0 = (icpt && q == 0) ? inv_scale : (double)buf[k][q].x;
+                u0 = __builtin_fma(c0, p0.x, u0);
+                u1 = __builtin_fma((double)buf[k][q].y, p0.y, u1);
+                u0 = __builtin_fma((double)buf[k][q].z, p1.x, u0);
+                u1 = __builtin_fma((double)buf[k][q].w, p1.y, u1);
+            }
+            const double u = wave_sum(u0 + u1);
+            double *pp = part + ((it & 1) * 8 + g) * 8;
+            if (lane == 0) pp[b] = active ? u : 0.0;
+            __syncthreads();
+            const double2 t01 = *reinterpret_cast<const double2 *>(pp), t23 = *reinterpret_cast<const double2 *>(pp + 2);
+            const double2 t45 = *reinterpret_cast<const double2 *>(pp + 4), t67 = *reinterpret_cast<const double2 *>(pp + 6);
+            const double us = (((t01.x + t01.y) + (t23.x + t23.y)) + ((t45.x + t45.y) + (t67.x + t67.y))) * s2;
+            if (active) {
+                #pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double c0 = (icpt && q == 0) ? inv_scale : (double)buf[k][q].x;
+                    ac[4 * q] = __builtin_fma(c0, us, ac[4 * q]);
+                    ac[4 * q + 1] = __builtin_fma((double)buf[k][q].y, us, ac[4 * q + 1]);
+                    ac[4 * q + 2] = __builtin_fma((double)buf[k][q].z, us, ac[4 * q + 2]);
+                    ac[4 * q + 3] = __builtin_fma((double)buf[k][q].w, us, ac[4 * q + 3]);
+                }
+            }
+            const long nrow = (it + RING) * nslots + slot;
+            if (nrow < a.n) load_row(nrow, buf[k]);      // refill this ring entry
+        }
+    }
+    double *slab = a.wpart + slot * 2 * a.F;
+    #pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const long f = fb + 128 * q;
+        if (f < a.F) *reinterpret_cast<double2 *>(slab + 2 * f) = make_double2(ac[4 * q], ac[4 * q + 1]);
+        if (f + 1 < a.F) *reinterpret_cast<double2 *>(slab + 2 * f + 2) = make_double2(ac[4 * q + 2], ac[4 * q + 3]);
     }
 }
 
@@ -1264,7 +1380,7 @@ int rbf_impl(const T *x, double *out, double *grad, const int8_t *radem, const T
             const long items = n * a.nb;
             const long nblocks = (items + 3) / 4;
             if (nblocks > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
-#define CALL_RBF(LG) hipLaunchKernelGGL(wave_rbf_kernel<LG>, dim3((unsigned)nblocks), dim3(256), 0, st, a)
+#define CALL_RBF(LG) hipLaunchKernelGGL((wave_rbf_kernel<LG, false>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
             DISPATCH_LOG2P(lg, CALL_RBF)
 #undef CALL_RBF
             HIP_TRY(hipGetLastError(), "wave_rbf_kernel launch");
@@ -1501,6 +1617,77 @@ int ztz_two_pass(const float *x, const int8_t *radem, const float *chi, const do
     return 0;
 }
 
+int zcache_build_impl(const float *x, float *zc, const int8_t *radem, const float *chi, long n, long d,
+                      long num_rffs, long num_freqs, long R, void *workspace, size_t wbytes, void *stream) {
+    const long P = padded_width(d);
+    if (n == 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (num_rffs < 2 || (num_rffs & 1) != 0) return fail(XGPR_ERR_ODD_OUTPUT, "last dim of output must be even number");
+    if (2 * num_freqs != num_rffs || num_freqs > R) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    if (R % P != 0) return fail(XGPR_ERR_RFFS_FREQS, "incorrect number of rffs and or freqs.");
+    if (P > 1024) return fail(XGPR_ERR_UNSUPPORTED, "the feature cache supports padded width <= 1024");
+    if (!workspace || wbytes < masks_bytes(R)) return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_rbf_workspace_bytes)");
+    if ((reinterpret_cast<uintptr_t>(zc) & 7) != 0) return fail(XGPR_ERR_WORKSPACE, "cache pointer must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    WaveArgs a = {};
+    a.x = x; a.outf = zc; a.masks = (const uint64_t *)workspace; a.chi = chi;
+    a.n = n; a.row_stride = d; a.F = num_freqs; a.d = (int)d;
+    a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
+    const int lg = ilog2(P);
+    fill_norms(a, lg);
+    int rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
+    if (rc) return rc;
+    const long nblocks = (n * a.nb + 3) / 4;
+    if (nblocks > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
+#define CALL_RBFC(LG) hipLaunchKernelGGL((wave_rbf_kernel<LG, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
+    DISPATCH_LOG2P(lg, CALL_RBFC)
+#undef CALL_RBFC
+    HIP_TRY(hipGetLastError(), "wave_rbf_kernel (cache) launch");
+    return 0;
+}
+
+int zcache_matvec_impl(const float *zc, const double *vec, double *w_out, long n, long num_rffs, int fit_intercept,
+                       void *workspace, size_t wbytes, void *stream) {
+    if (n == 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (num_rffs < 2 || (num_rffs & 1) != 0) return fail(XGPR_ERR_ODD_OUTPUT, "last dim of output must be even number");
+    const long F = num_rffs / 2;
+    if (F > 8192) return fail(XGPR_ERR_UNSUPPORTED, "cached matvec supports num_freqs <= 8192");
+    if (!aligned16(vec) || !aligned16(w_out) || !aligned16(zc)) return fail(XGPR_ERR_WORKSPACE, "pointers must be 16-byte aligned");
+    const size_t need = (size_t)ZTZ_MAX_SLABS * num_rffs * sizeof(double);
+    if (!workspace || wbytes < need || !aligned16(workspace))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_ztz_matvec_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    ZcArgs a = {};
+    a.zc = zc; a.vec = vec; a.wpart = reinterpret_cast<double *>(workspace);
+    a.n = n; a.F = F; a.nb = (int)((F + 1023) / 1024);
+    a.G = 8 / a.nb;                                // 8 waves per workgroup = 2 per SIMD, deep register rings
+    if ((long)a.G > n) a.G = (int)n;
+    a.fit_intercept = fit_intercept;
+    a.scale = rbf_scale<float>(F, fit_intercept);
+    const int waves = a.nb * a.G;
+    long nblocks = device_cus();
+    const long max_by_rows = (n + a.G - 1) / a.G;
+    if (nblocks > max_by_rows) nblocks = max_by_rows;
+    if (nblocks * a.G > ZTZ_MAX_SLABS) nblocks = ZTZ_MAX_SLABS / a.G;
+    constexpr int RING = 2;     // measured: 6.3 TB/s with 2 (222 VGPRs), 6.0 with 3, 3.8 with 4 (spills)
+    const size_t lds = (size_t)a.nb * 1024 * 16 + 2 * 8 * 8 * sizeof(double);
+    if (F % 2 == 0) {
+        auto kern = zcache_ztz_kernel<true, RING>;
+        int rc = allow_big_lds(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(waves * 64), lds, st, a);
+    } else {
+        auto kern = zcache_ztz_kernel<false, RING>;
+        int rc = allow_big_lds(kern, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(waves * 64), lds, st, a);
+    }
+    HIP_TRY(hipGetLastError(), "zcache_ztz_kernel launch");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((num_rffs + 63) / 64)), dim3(256), 0, st, a.wpart, w_out,
+                       num_rffs, nblocks * a.G);
+    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -1663,6 +1850,16 @@ int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefac
                        M, rank);
     HIP_TRY(hipGetLastError(), "precond_uz_kernel launch");
     return 0;
+}
+
+int xgpr_rbf_feature_cache_f32(const float *x, float *zc, const int8_t *radem, const float *chi, long n, long d,
+                               long num_rffs, long num_freqs, long radem_shape2, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    return zcache_build_impl(x, zc, radem, chi, n, d, num_rffs, num_freqs, radem_shape2, workspace, workspace_bytes, stream);
+}
+int xgpr_zcache_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs, int fit_intercept,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+    return zcache_matvec_impl(zc, v, w_out, n, num_rffs, fit_intercept, workspace, workspace_bytes, stream);
 }
 
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {

@@ -71,6 +71,19 @@ class DeviceDataset:
             lchunk = None if self._sequence_lengths is None else self._sequence_lengths[i:j]
             yield self._xdata[i:j, ...], lchunk
 
+    def feature_cache(self, kernel):
+        """float32 feature cache of the whole shard for ``kernel`` at its current sigma (rebuilt when
+        the kernel object or sigma changes)."""
+        key = (id(kernel), float(kernel.hyperparams[1]))
+        if getattr(self, "_zcache_key", None) != key:
+            self._zcache = None
+            self._zcache = kernel.build_feature_cache(self.scaled_x(kernel.hyperparams[1]))
+            self._zcache_key = key
+        return self._zcache
+
+    def feature_cache_bytes(self, kernel):
+        return self._xdata.shape[0] * kernel.get_num_rffs() * 4
+
     def scaled_x(self, sigma):
         """The whole shard pre-multiplied by sigma (what ``transform_x`` does to each chunk
         copy, sorf_kernel_baseclass.py:117), cached per sigma for the fused kernels."""

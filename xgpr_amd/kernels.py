@@ -126,6 +126,20 @@ class SORFKernel(KernelBase):
     def zty(self, x_scaled, y, out, workspace=None):
         ext.hipZtY(x_scaled, self.radem_diag, self.chi_arr, y, out, self.fit_intercept, workspace)
 
+    # ---- resident feature cache: keep the shard's Z in HBM as float32 (cos, sin) pairs and stream
+    # it on every CG iteration instead of regenerating it (an option the 288 GB of HBM3E allow;
+    # the reference cannot hold Z and regenerates it, cg_tools.py:189-191)
+    def cache_ok(self):
+        return self.fused_ok() and self.num_freqs <= 8192
+
+    def build_feature_cache(self, x_scaled):
+        zc = torch.empty((x_scaled.shape[0], self.num_rffs), dtype=torch.float32, device=self.device)
+        ext.hipRBFFeatureCache(x_scaled, zc, self.radem_diag, self.chi_arr)
+        return zc
+
+    def ztz_matvec_cached(self, zcache, vec, out, workspace):
+        ext.hipZCacheMatvec(zcache, vec, out, self.fit_intercept, workspace)
+
     def fused_ok(self):
         """The fused kernels cover padded width <= 1024 (single pass up to num_freqs = 8192, the
         two-pass form beyond, up to 65536)."""

@@ -271,6 +271,32 @@ def precond_workspace_bytes(rank):
     return int(_LIB.xgpr_precond_apply_workspace_bytes(rank))
 
 
+def hipRBFFeatureCache(inputArr, cacheArr, radem, chiArr):
+    """float32 (cos, sin) pairs before scaling, cacheArr [N, num_rffs] float32 (see include/xgpr_hip.h)."""
+    x = _dev(inputArr, "inputArr", torch.float32, 2)
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    r = _radem3(radem)
+    c = _dev(chiArr, "chiArr", torch.float32, 1)
+    if cacheArr.shape[0] != inputArr.shape[0]:
+        raise RuntimeError("no datapoints")
+    ws, wp, wn = _sorf_ws(radem, inputArr.shape[1], inputArr)
+    return _lib.check(_LIB.xgpr_rbf_feature_cache_f32(
+        x, zc, r, c, inputArr.shape[0], inputArr.shape[1], cacheArr.shape[1], chiArr.shape[0], radem.shape[2],
+        wp, wn, _stream()))
+
+
+def hipZCacheMatvec(cacheArr, vec, outVec, fitIntercept, workspace):
+    """``Z.T @ (Z @ vec)`` streamed from the resident feature cache (cg_tools.py:189-191)."""
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    v = _dev(vec, "vec", torch.float64, 1)
+    o = _dev(outVec, "outVec", torch.float64, 1)
+    if vec.shape[0] != cacheArr.shape[1] or outVec.shape[0] != cacheArr.shape[1]:
+        raise TypeError("vec / outVec: expected num_rffs entries")
+    return _lib.check(_LIB.xgpr_zcache_matvec_f32(
+        zc, v, o, cacheArr.shape[0], cacheArr.shape[1], int(bool(fitIntercept)),
+        C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
+
+
 def ztz_workspace_bytes(num_rffs, radem_shape2):
     return int(_LIB.xgpr_ztz_matvec_workspace_bytes(num_rffs, radem_shape2))
 
