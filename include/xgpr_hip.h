@@ -201,6 +201,11 @@ int xgpr_rbf_feature_cache_f32(const float *x, float *zc, const int8_t *radem, c
                                void *workspace, size_t workspace_bytes, void *stream);
 int xgpr_zcache_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs,
                            int fit_intercept, void *workspace, size_t workspace_bytes, void *stream);
+/* the same over a cache that holds any kernel's feature rows z_i / scale as float32 (e.g. the
+ * Conv1d / graph kernels' transform_x output rounded to float32, scale = 1, intercept column
+ * already set): w_out = scale^2 * sum_i c_i (c_i . v). */
+int xgpr_zcache_matvec_scaled_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs,
+                                  double scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- self test of the cross-lane butterfly stages the wave-level FHT is built on: for each
  * of the 6 lane strides h = 1, 2, 4, 8, 16, 32 runs one stage on v[r] = lane + 64 r

@@ -218,3 +218,28 @@ def test_cg_with_resident_feature_cache_matches_regenerating_cg():
     assert n0 == n1 == int(g["Matern_srht_niter"])
     assert rel(w1, w0.cpu().numpy()) < 1e-8      # float64 summation order differs between the two kernels
     assert rel(w1, g["Matern_srht_weights"]) < 1e-5
+
+
+def test_conv_cg_with_feature_cache_matches_oracle(oracle):
+    """Conv1d kernel, CG with the resident (float32) feature cache -- the configuration that matters
+    for sequence kernels, where regenerating Z costs K k-mers x SORF per sequence per iteration --
+    against the oracle's CG on regenerated float64 features."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import cg_fit_lib_internal
+    rng = np.random.default_rng(5)
+    n, L, C = 400, 24, 8
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(5, L + 1, size=n).astype(np.int32)
+    y = rng.standard_normal(n)
+    hp = np.array([0.5, 0.7])
+    ds = build_regression_dataset(x, y, sl, chunk_size=128, device=DEV)
+    kern = make_kernel("Conv1dRBF", x.shape, 256, 123, DEV, {"conv_width": 5, "averaging": "sqrt"})
+    kern.set_hyperparams(hp, logspace=False)
+    w, niter, _ = cg_fit_lib_internal(kern, ds, 1e-9, 300, None, False, cache_features=True)
+    ods = orc.OracleDataset(x.astype(np.float64), y, sl, chunk_size=128)
+    okern = orc.OracleKernel("Conv1dRBF", 256, x.shape, hp, 123, conv_width=5, averaging="sqrt", ops=oracle)
+    wref, nref, _, _ = orc.cg_fit_lib_internal(okern, ods, 1e-9, 300, None)
+    assert abs(niter - nref) <= 1
+    assert rel(w, wref) < 1e-5

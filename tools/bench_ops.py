@@ -43,8 +43,9 @@ def main():
         print(f"fused ZtZ matvec  d={d:5d} M={m:6d} n={n}: {ms:8.3f} ms  {n / ms / 1e3:8.1f} Mrows/s  "
               f"{n * m / ms / 1e6:8.1f} Gfeat/s  X-read {4 * d * n / ms / 1e6:7.1f} GB/s")
         if k.cache_ok():
-            zc = k.build_feature_cache(x)
-            ms = timeit(lambda: k.build_feature_cache(x), reps=2, warm=0)
+            from xgpr_amd import xgpr_hip_rfgen_ext as _e
+            zc = torch.empty((n, m), dtype=torch.float32, device=dev)
+            ms = timeit(lambda: _e.hipRBFFeatureCache(x, zc, k.radem_diag, k.chi_arr), reps=2, warm=1)
             print(f"feature cache     d={d:5d} M={m:6d} n={n}: {ms:8.3f} ms  {n / ms / 1e3:8.1f} Mrows/s  "
                   f"HBM {(4 * d + 4 * m) * n / ms / 1e6:7.1f} GB/s")
             ms = timeit(lambda: k.ztz_matvec_cached(zc, v, out, ws))

@@ -39,6 +39,7 @@ SIGNATURES = {
     "xgpr_precond_apply_f64": [_vp, _vp, _d, _vp, _vp, _l, _l, _vp, _sz, _vp],
     "xgpr_rbf_feature_cache_f32": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _vp, _sz, _vp],
     "xgpr_zcache_matvec_f32": [_vp, _vp, _vp, _l, _l, _i, _vp, _sz, _vp],
+    "xgpr_zcache_matvec_scaled_f32": [_vp, _vp, _vp, _l, _l, _d, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
 }
 SIZE_FUNCS = {

@@ -78,14 +78,16 @@ class ConjugateGrad:
     def _ztz(self, dataset, kernel, vec, out):
         """out <- sum over ranks of Z^T (Z vec) for one right-hand side (fused kernel +
         all-reduce); lambda^2 vec is added by the caller."""
-        xs = dataset.scaled_x(kernel.hyperparams[1])
-        if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != xs.device:
-            self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=xs.device)
-        if self.cache_features and kernel.cache_ok():
+        if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != out.device:
+            self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=out.device)
+        if self._use_cache(kernel):
             kernel.ztz_matvec_cached(dataset.feature_cache(kernel), vec, out, self._ws)
         else:
-            kernel.ztz_matvec(xs, vec, out, self._ws)
+            kernel.ztz_matvec(dataset.scaled_x(kernel.hyperparams[1]), vec, out, self._ws)
         self.comm.all_reduce_(out)
+
+    def _use_cache(self, kernel):
+        return self.cache_features and hasattr(kernel, "cache_ok") and kernel.cache_ok()
 
     def _fit_one_rhs_device(self, dataset, kernel, preconditioner, resid, maxiter, tol, verbose, trace):
         """The k = 1 regression solve on the device with the vector updates of
@@ -171,7 +173,8 @@ class ConjugateGrad:
         right-hand side; starting weights are zero.  Returns (x_k, converged, niter, losses),
         or (x_k, alphas, betas) with ``nmll_settings``."""
         dev = resid.device
-        if (resid.shape[2] == 1 and not nmll_settings and dev.type == "cuda" and kernel.fused_ok()
+        if (resid.shape[2] == 1 and not nmll_settings and dev.type == "cuda"
+                and (kernel.fused_ok() or self._use_cache(kernel))
                 and (preconditioner is None or hasattr(preconditioner, "u_mat"))):
             return self._fit_one_rhs_device(dataset, kernel, preconditioner, resid, maxiter, tol, verbose, trace)
         converged = False

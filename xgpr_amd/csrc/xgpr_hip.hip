@@ -1646,7 +1646,7 @@ int zcache_build_impl(const float *x, float *zc, const int8_t *radem, const floa
 }
 
 int zcache_matvec_impl(const float *zc, const double *vec, double *w_out, long n, long num_rffs, int fit_intercept,
-                       void *workspace, size_t wbytes, void *stream) {
+                       double scale_override, void *workspace, size_t wbytes, void *stream) {
     if (n == 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
     if (num_rffs < 2 || (num_rffs & 1) != 0) return fail(XGPR_ERR_ODD_OUTPUT, "last dim of output must be even number");
     const long F = num_rffs / 2;
@@ -1662,7 +1662,7 @@ int zcache_matvec_impl(const float *zc, const double *vec, double *w_out, long n
     a.G = 8 / a.nb;                                // 8 waves per workgroup = 2 per SIMD, deep register rings
     if ((long)a.G > n) a.G = (int)n;
     a.fit_intercept = fit_intercept;
-    a.scale = rbf_scale<float>(F, fit_intercept);
+    a.scale = scale_override > 0.0 ? scale_override : rbf_scale<float>(F, fit_intercept);
     const int waves = a.nb * a.G;
     long nblocks = device_cus();
     const long max_by_rows = (n + a.G - 1) / a.G;
@@ -1859,7 +1859,12 @@ int xgpr_rbf_feature_cache_f32(const float *x, float *zc, const int8_t *radem, c
 }
 int xgpr_zcache_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs, int fit_intercept,
                            void *workspace, size_t workspace_bytes, void *stream) {
-    return zcache_matvec_impl(zc, v, w_out, n, num_rffs, fit_intercept, workspace, workspace_bytes, stream);
+    return zcache_matvec_impl(zc, v, w_out, n, num_rffs, fit_intercept, 0.0, workspace, workspace_bytes, stream);
+}
+int xgpr_zcache_matvec_scaled_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs, double scale,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    if (!(scale > 0.0)) return fail(XGPR_ERR_ARRAY_DIMS, "scale must be positive");
+    return zcache_matvec_impl(zc, v, w_out, n, num_rffs, 0, scale, workspace, workspace_bytes, stream);
 }
 
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {

@@ -77,7 +77,7 @@ class DeviceDataset:
         key = (id(kernel), float(kernel.hyperparams[1]))
         if getattr(self, "_zcache_key", None) != key:
             self._zcache = None
-            self._zcache = kernel.build_feature_cache(self.scaled_x(kernel.hyperparams[1]))
+            self._zcache = kernel.build_feature_cache(self)
             self._zcache_key = key
         return self._zcache
 

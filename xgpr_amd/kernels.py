@@ -132,7 +132,8 @@ class SORFKernel(KernelBase):
     def cache_ok(self):
         return self.fused_ok() and self.num_freqs <= 8192
 
-    def build_feature_cache(self, x_scaled):
+    def build_feature_cache(self, dataset):
+        x_scaled = dataset.scaled_x(self.hyperparams[1])
         zc = torch.empty((x_scaled.shape[0], self.num_rffs), dtype=torch.float32, device=self.device)
         ext.hipRBFFeatureCache(x_scaled, zc, self.radem_diag, self.chi_arr)
         return zc
@@ -206,6 +207,30 @@ class ConvSORFKernel(KernelBase):
 
     def fused_ok(self):
         return False
+
+    # ---- resident feature cache.  Convolution features cost K k-mers x a full SORF per sequence, so
+    # regenerating them on every CG iteration (what the reference does) is by far the most expensive
+    # way to apply Z; here the shard's Z (kernel_baseclass.py:269-299 output, intercept column set)
+    # is rounded to float32 once -- entries are sums of float32 cos/sin values, so this adds at most
+    # 6e-8 relative per entry -- and streamed from HBM afterwards.
+    def cache_ok(self):
+        return self.num_freqs <= 8192
+
+    def build_feature_cache(self, dataset):
+        n = dataset.get_local_ndatapoints()
+        zc = torch.empty((n, self.num_rffs), dtype=torch.float32, device=self.device)
+        row = 0
+        for x, lengths in dataset.get_chunked_x_data():
+            z = self.transform_x(x, lengths)
+            zc[row:row + z.shape[0]] = z.to(torch.float32)
+            row += z.shape[0]
+        return zc
+
+    def ztz_matvec_cached(self, zcache, vec, out, workspace):
+        ext.hipZCacheMatvecScaled(zcache, vec, out, 1.0, workspace)
+
+    def workspace_bytes(self):
+        return ext.ztz_workspace_bytes(self.num_rffs, self.radem_diag.shape[2])
 
     def kernel_specific_transform(self, input_x, sequence_length):
         """conv_kernel_baseclass.py:116-147."""

@@ -285,6 +285,18 @@ def hipRBFFeatureCache(inputArr, cacheArr, radem, chiArr):
         wp, wn, _stream()))
 
 
+def hipZCacheMatvecScaled(cacheArr, vec, outVec, scale, workspace):
+    """``Z.T @ (Z @ vec)`` with Z = scale * cacheArr (any kernel's float32 feature rows)."""
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    v = _dev(vec, "vec", torch.float64, 1)
+    o = _dev(outVec, "outVec", torch.float64, 1)
+    if vec.shape[0] != cacheArr.shape[1] or outVec.shape[0] != cacheArr.shape[1]:
+        raise TypeError("vec / outVec: expected num_rffs entries")
+    return _lib.check(_LIB.xgpr_zcache_matvec_scaled_f32(
+        zc, v, o, cacheArr.shape[0], cacheArr.shape[1], float(scale),
+        C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
+
+
 def hipZCacheMatvec(cacheArr, vec, outVec, fitIntercept, workspace):
     """``Z.T @ (Z @ vec)`` streamed from the resident feature cache (cg_tools.py:189-191)."""
     zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
