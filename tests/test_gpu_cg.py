@@ -50,7 +50,8 @@ def test_g7_cg_iterates(kname, parms):
             assert np.allclose(pu, u_ref @ (u_ref.T @ v), atol=1e-5)
         ref_it = g[f"{kname}_{ptag}_iterates"]
         trace = {}
-        w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-30, ref_it.shape[0], pre, False, trace=trace)
+        w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-30, ref_it.shape[0], pre, False, trace=trace,
+                                               cache_features=False)
         n = ds.get_ndatapoints()
         errs = np.array([rel(trace["x_k"][j][:, 0] * n, ref_it[j]) for j in range(ref_it.shape[0])])
         print(f"{kname} {ptag}: iterate rel err " + " ".join(f"{e:.1e}" for e in errs))
@@ -213,7 +214,7 @@ def test_cg_with_resident_feature_cache_matches_regenerating_cg():
     kern = make_kernel("Matern", x.shape, int(g["num_rffs"]), 123, DEV, {"matern_nu": 2.5})
     kern.set_hyperparams(g["hyperparams"], logspace=False)
     pre = RandNysPreconditioner(kern, ds, 64, False, 123, "srht")
-    w0, n0, _ = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False)
+    w0, n0, _ = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False, cache_features=False)
     w1, n1, _ = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False, cache_features=True)
     assert n0 == n1 == int(g["Matern_srht_niter"])
     assert rel(w1, w0.cpu().numpy()) < 1e-8      # float64 summation order differs between the two kernels

@@ -238,11 +238,25 @@ class ConjugateGrad:
         return x_k[:, 0], converged, niter + 1, losses
 
 
+def _resolve_cache_mode(cache_features, kernel, dataset):
+    """"auto": keep Z resident when the kernel supports it and the float32 cache of this shard fits
+    comfortably in free HBM (it then needs cache + 2 GB with 1.5x headroom)."""
+    if cache_features != "auto":
+        return bool(cache_features)
+    if not (hasattr(kernel, "cache_ok") and kernel.cache_ok()) or torch.device(kernel.device).type != "cuda":
+        return False
+    free, _total = torch.cuda.mem_get_info(torch.device(kernel.device))
+    return 1.5 * dataset.feature_cache_bytes(kernel) + 2e9 < free
+
+
 def cg_fit_lib_internal(kernel, dataset, cg_tol=1e-4, max_iter=500, preconditioner=None,
-                        verbose=True, trace=None, cache_features=False):
-    """cg_fitting_toolkit.py:18-70 -> (weights [M] f64 device, n_iter, losses)."""
+                        verbose=True, trace=None, cache_features="auto"):
+    """cg_fitting_toolkit.py:18-70 -> (weights [M] f64 device, n_iter, losses).
+    ``cache_features``: False = regenerate the features on every iteration (what the reference does);
+    True = keep the shard's Z resident in HBM as float32 and stream it; "auto" (default) = resident
+    when it fits.  The solve is the same either way (same iteration count, weights to ~1e-9)."""
     comm = dataset.comm
-    cg_operator = ConjugateGrad(comm, cache_features)
+    cg_operator = ConjugateGrad(comm, _resolve_cache_mode(cache_features, kernel, dataset))
     resid = torch.zeros((kernel.get_num_rffs(), 2, 1), dtype=torch.float64, device=kernel.device)
     if preconditioner is None:
         z_trans_y, _ = calc_zty(dataset, kernel)
