@@ -213,11 +213,17 @@ def main():
         ck_ms = float(np.mean([a.elapsed_time(b) for a, b in ctimes]))
         kern.ztz_matvec_cached = origc
         cbytes = 4.0 * m * (hi - lo)
+        ctraffic = None
+        try:   # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (profiles/r1_pmc_traffic_cached.json)
+            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
+        except (OSError, KeyError, ValueError):
+            pass
         cached = {"ms_per_step": 1e3 * float(tc.item()) / args.steps, "cg_iters_per_sec": args.steps / float(tc.item()),
                   "cache_bytes_per_gpu": cbytes, "cache_build_s": cache_build_s,
                   "roofline": {"kernel": "zcache_ztz_kernel<true, 2> (+ reduce_slabs)", "bound": "hbm",
                                "achieved": cbytes / (ck_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": cbytes / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ck_ms},
+                               "frac": cbytes / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ctraffic,
+                               "algorithmic_bytes": cbytes, "kernel_ms": ck_ms},
                   "note": "features generated once (cache_build_s) and streamed; NOT the headline number"}
         del zc
         ds._zcache = None
