@@ -166,16 +166,14 @@ int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const do
 
 /* ---- fused CG vector updates for one right-hand side: the per-iteration arithmetic of
  * CPU/GPU_ConjugateGrad.fit (src/xGPR/fitting_toolkit/cg_tools.py:255-274 / :108-127) between
- * the matvec and the next search direction, as two single-workgroup kernels.  All vectors are
+ * the matvec and the next search direction, as two single-workgroup kernels (the preconditioner apply
+ * between them is xgpr_precond_apply_f64).  All vectors are
  * float64 [M] on the device; scal is float64 [4] = { r.z, alpha, err, beta }.
  *   step1: w += lam2 * p (w arrives holding the all-reduced Z^T Z p); alpha = (r.z)/(p.w);
  *          x += alpha p; r_next = r - alpha w; err = |r| / init_norm   (cg_tools.py:256-265)
- *   precond_scale: t[j] = (inv_eig[j] * prefactor - 1) * t[j]  -- the diagonal between the two
- *          U products of RandNysPreconditioner.batch_matvec (rand_nys_preconditioners.py:66-72)
  *   step2: beta = (r_next.z_next)/(r.z); p_next = z_next + beta p     (cg_tools.py:271-274) */
 int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next,
                       const double *z, double *scal, double lam2, double init_norm, long M, void *stream);
-int xgpr_precond_scale_f64(double *t, const double *inv_eig, double prefactor, long rank, void *stream);
 int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *p, double *p_next,
                       double *scal, long M, void *stream);
 

@@ -1134,14 +1134,6 @@ __global__ __launch_bounds__(1024) void cg_step1_kernel(double *w, const double 
     if (threadIdx.x == 0) { scal[0] = rz; scal[1] = alpha; scal[2] = sqrt(rr) / init_norm; }
 }
 
-// between the steps: z_next = r_next + U ((inv_eig * prefactor - 1) .* (U^T r_next)) is two library
-// GEMVs (rand_nys_preconditioners.py:66-72 with the two U products merged); this kernel scales the
-// rank-sized vector in between: t[j] = (inv_eig[j] * prefactor - 1) * t[j].
-__global__ void precond_scale_kernel(double *t, const double *__restrict__ inv_eig, double prefactor, long rank) {
-    long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < rank) t[j] = (inv_eig[j] * prefactor - 1.0) * t[j];
-}
-
 // step 2 (cg_tools.py:271-274): beta = (r_next.z_next)/(r.z) ; p_next = z_next + beta p.  scal[3] = beta.
 __global__ __launch_bounds__(1024) void cg_step2_kernel(const double *__restrict__ r_next, const double *__restrict__ z_next,
                                                         const double *__restrict__ p, double *p_next, double *scal, long M) {
@@ -1815,13 +1807,6 @@ int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, do
     hipLaunchKernelGGL(cg_step1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, p, x, r, r_next, z, scal, lam2,
                        init_norm, M);
     HIP_TRY(hipGetLastError(), "cg_step1_kernel launch");
-    return 0;
-}
-int xgpr_precond_scale_f64(double *t, const double *inv_eig, double prefactor, long rank, void *stream) {
-    if (rank <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
-    hipLaunchKernelGGL(precond_scale_kernel, dim3((unsigned)((rank + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t,
-                       inv_eig, prefactor, rank);
-    HIP_TRY(hipGetLastError(), "precond_scale_kernel launch");
     return 0;
 }
 int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *p, double *p_next, double *scal, long M,

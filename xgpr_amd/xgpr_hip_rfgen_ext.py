@@ -233,13 +233,6 @@ def hipCGStep1(w, p, x, r, r_next, z, scal, lam2, init_norm):
         float(init_norm), w.shape[0], _stream()))
 
 
-def hipPrecondScale(t, inv_eig, prefactor):
-    _dev(t, "t", torch.float64, 1)
-    _dev(inv_eig, "inv_eig", torch.float64, 1)
-    return _lib.check(_LIB.xgpr_precond_scale_f64(C.c_void_p(t.data_ptr()), C.c_void_p(inv_eig.data_ptr()),
-                                                  float(prefactor), t.shape[0], _stream()))
-
-
 def hipCGStep2(r_next, z_next, p, p_next, scal):
     """cg_tools.py:271-274 for one right-hand side."""
     for name, t in (("r_next", r_next), ("z_next", z_next), ("p", p), ("p_next", p_next)):
