@@ -304,3 +304,40 @@ def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
     out2 = torch.zeros_like(out)
     ext.hipZCacheMatvec(zc, dev(v), out2, icpt, ws)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("d,rffs,icpt,n", [(50, 128, False, 11), (256, 4096, True, 30), (856, 4000, True, 7),
+                                           (1024, 8192, False, 9), (1100, 2048, True, 5)])
+def test_rbf_grad_vs_oracle(ext, oracle, d, rffs, icpt, n):
+    """cudaRBFGrad on the wave path (P <= 1024) and the generic path: features and d/dsigma against
+    the oracle, including the reference's roundings back to float (shared_rfgen_ops.cpp:140-155)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(d + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, d, 17)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    sigma = 1.7
+    ro, rg = np.zeros((n, rffs)), np.zeros((n, rffs, 1))
+    oracle.cpuRBFGrad(x.copy(), ro, rg, radem, chi, sigma, icpt)
+    o = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+    g = torch.zeros((n, rffs, 1), dtype=torch.float64, device=DEV)
+    ext.hipRBFGrad(dev(x), o, g, dev(radem), dev(chi), sigma, icpt)
+    scale = np.sqrt(2.0 / rffs)
+    assert np.abs(o.cpu().numpy() - ro).max() <= 4e-7 * scale
+    assert np.abs(g.cpu().numpy() - rg).max() <= 1e-6 * np.abs(rg).max()
+
+
+@pytest.mark.parametrize("L,C,cw,rffs,sc,n", [(30, 21, 9, 1024, 1, 9), (17, 4, 1, 64, 0, 21), (40, 21, 5, 600, 2, 7)])
+def test_conv_grad_vs_oracle(ext, oracle, L, C, cw, rffs, sc, n):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(L * C + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, cw * C, 77, conv=True)
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(cw, L + 1, size=n).astype(np.int32)
+    sigma = 0.8
+    ro, rg = np.zeros((n, rffs)), np.zeros((n, rffs, 1))
+    oracle.cpuConvGrad(x, ro, radem, chi, sl, rg, sigma, cw, sc)
+    o = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+    g = torch.zeros((n, rffs, 1), dtype=torch.float64, device=DEV)
+    ext.hipConvGrad(dev(x), o, dev(radem), dev(chi), sl, g, sigma, cw, sc)
+    assert np.abs(o.cpu().numpy() - ro).max() <= 1e-6 * np.abs(ro).max()
+    assert np.abs(g.cpu().numpy() - rg).max() <= 1e-6 * np.abs(rg).max()

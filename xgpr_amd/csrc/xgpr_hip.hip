@@ -616,13 +616,17 @@ struct WaveArgs {
     double scale;
     double *tpart;            // two-pass matvec: per-(datapoint, tile) partial dots [rows, nb]
     int add_to_slab;          // two-pass matvec: slabs accumulate over row windows
+    double *grad; double sigma;   // gradient operators
 };
 
 // ---- cudaRBFFeatureGen: one wave per (datapoint, tile); 4 waves per workgroup.  With CACHE the
 // kernel writes the float32 (cos, sin) pairs before scaling -- the exact values the float64
 // output is the widening of -- into a.outf [n, 2F] (the resident feature cache).
-template <int LOG2P, bool CACHE>
+enum { OUT_F64 = 0, OUT_CACHE = 1, OUT_GRAD = 2 };
+
+template <int LOG2P, int OUT>
 __global__ __launch_bounds__(256) void wave_rbf_kernel(WaveArgs a) {
+    constexpr bool CACHE = OUT == OUT_CACHE;
     const int lane = threadIdx.x & 63;
     const long item = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (long)blockIdx.x * 4;
     if (item >= a.n * a.nb) return;
@@ -644,6 +648,26 @@ __global__ __launch_bounds__(256) void wave_rbf_kernel(WaveArgs a) {
         const long f = f0 + r * 64;
         const float ch = a.chi[(full || f < a.F) ? f : 0];
         arg[r] = v[r] * (ch * a.chi_scale);
+    }
+    if constexpr (OUT == OUT_GRAD) {
+        // cudaRBFGrad: shared_rfgen_ops.cpp:140-155 with its roundings back to float; the input is
+        // not pre-multiplied by sigma, and the scale is a double here (rbf_ops.cpp:180-185)
+        float gv[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { gv[r] = arg[r]; arg[r] = (float)(gv[r] * a.sigma); }
+        tile_sincos(arg, sn, cs);
+        double *orow = a.out + i * 2 * a.F, *grow = a.grad + i * 2 * a.F;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long f = f0 + r * 64;
+            if (full || f < a.F) {
+                const float cos_val = (float)(cs[r] * a.scale), sin_val = (float)(sn[r] * a.scale);
+                const float gs = sin_val * gv[r], gc = cos_val * gv[r];
+                *reinterpret_cast<double2 *>(orow + 2 * f) = make_double2(cos_val, sin_val);
+                *reinterpret_cast<double2 *>(grow + 2 * f) = make_double2(-(double)gs, gc);
+            }
+        }
+        return;
     }
     tile_sincos(arg, sn, cs);
     if constexpr (CACHE) {
@@ -716,6 +740,44 @@ __global__ __launch_bounds__(256) void wave_conv_kernel(WaveArgs a) {
         for (int r = 0; r < 16; r++) {
             const long f = f0 + r * 64;
             if (f < a.F) orow[f] = acc[r];
+        }
+    } else if (a.grad) {
+        // cudaConvGrad: per k-mer the roundings of shared_rfgen_ops.cpp:140-155 (values rounded back
+        // to float before they are accumulated), sums over k-mers in float64 in the reference's order
+        double rs = a.scale;
+        if (a.scaling_type == 1) rs = a.scale / sqrt((double)nk);
+        else if (a.scaling_type == 2) rs = a.scale / (double)nk;
+        double oc[16], os[16], gc[16], gs[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { oc[r] = 0.0; os[r] = 0.0; gc[r] = 0.0; gs[r] = 0.0; }
+        for (int j = 0; j < nk; j++) {
+            mk = launder(mk);
+            float v[16], gv[16], sn[16], cs[16];
+            wave_load<LOG2P>(v, xrow + (long)j * a.kmer_stride, a.d, lane);
+            tile_sorf<LOG2P, TP>(v, mk, sw, tb, a.MW, a.nc, lane);
+            #pragma unroll
+            for (int r = 0; r < 16; r++) { gv[r] = v[r] * ch[r]; v[r] = (float)(gv[r] * a.sigma); }
+            tile_sincos(v, sn, cs);
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float cos_val = (float)(cs[r] * rs), sin_val = (float)(sn[r] * rs);
+                oc[r] += cos_val;
+                os[r] += sin_val;
+                gc[r] -= sin_val * gv[r];
+                gs[r] += cos_val * gv[r];
+            }
+        }
+        double *orow = a.out + i * 2 * a.F, *grow = a.grad + i * 2 * a.F;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long f = f0 + r * 64;
+            if (f < a.F) {
+                double2 *o = reinterpret_cast<double2 *>(orow + 2 * f), *g = reinterpret_cast<double2 *>(grow + 2 * f);
+                double2 ov = *o, gvv = *g;
+                ov.x += oc[r]; ov.y += os[r];
+                gvv.x += gc[r]; gvv.y += gs[r];
+                *o = ov; *g = gvv;
+            }
         }
     } else {
         double ac[16], as[16];
@@ -1358,13 +1420,18 @@ int rbf_impl(const T *x, double *out, double *grad, const int8_t *radem, const T
     const int reps = (int)((num_freqs + P - 1) / P);
 
     if constexpr (sizeof(T) == 4) {
-        if (!want_grad && P <= 1024) {
+        if (P <= 1024) {
             if (!workspace || wbytes < masks_bytes(R)) return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_rbf_workspace_bytes)");
             WaveArgs a = {};
             a.x = x; a.out = out; a.masks = (const uint64_t *)workspace; a.chi = chi;
             a.n = n; a.row_stride = d; a.F = num_freqs; a.d = (int)d;
             a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
             a.scale = rbf_scale<float>(num_freqs, fit_intercept);
+            if (want_grad) {
+                if (!aligned16(grad)) return fail(XGPR_ERR_WORKSPACE, "gradient pointer must be 16-byte aligned");
+                a.grad = grad; a.sigma = sigma;
+                a.scale = fit_intercept ? sqrt(1.0 / ((double)num_freqs - 0.5)) : sqrt(1.0 / (double)num_freqs);
+            }
             const int lg = ilog2(P);
             fill_norms(a, lg);
             int rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
@@ -1372,9 +1439,15 @@ int rbf_impl(const T *x, double *out, double *grad, const int8_t *radem, const T
             const long items = n * a.nb;
             const long nblocks = (items + 3) / 4;
             if (nblocks > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
-#define CALL_RBF(LG) hipLaunchKernelGGL((wave_rbf_kernel<LG, false>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
-            DISPATCH_LOG2P(lg, CALL_RBF)
+            if (want_grad) {
+#define CALL_RBFG(LG) hipLaunchKernelGGL((wave_rbf_kernel<LG, OUT_GRAD>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
+                DISPATCH_LOG2P(lg, CALL_RBFG)
+#undef CALL_RBFG
+            } else {
+#define CALL_RBF(LG) hipLaunchKernelGGL((wave_rbf_kernel<LG, OUT_F64>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
+                DISPATCH_LOG2P(lg, CALL_RBF)
 #undef CALL_RBF
+            }
             HIP_TRY(hipGetLastError(), "wave_rbf_kernel launch");
             return 0;
         }
@@ -1419,8 +1492,9 @@ int conv_impl(const T *x, double *out, double *grad, float *outf, const int8_t *
     hipStream_t st = (hipStream_t)stream;
 
     if constexpr (sizeof(T) == 4) {
-        if ((mode == MODE_CONV || mode == MODE_MAXPOOL) && P <= 1024) {
-            if (mode == MODE_CONV && !aligned16(out)) return fail(XGPR_ERR_WORKSPACE, "output pointer must be 16-byte aligned");
+        if (P <= 1024) {
+            if (mode != MODE_MAXPOOL && !aligned16(out)) return fail(XGPR_ERR_WORKSPACE, "output pointer must be 16-byte aligned");
+            if (mode == MODE_CONV_GRAD && !aligned16(grad)) return fail(XGPR_ERR_WORKSPACE, "gradient pointer must be 16-byte aligned");
             if (!workspace || wbytes < masks_bytes(R)) return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_rbf_workspace_bytes)");
             WaveArgs a = {};
             a.x = x; a.out = out; a.outf = outf; a.masks = (const uint64_t *)workspace; a.chi = chi; a.seqlen = seqlen_dev;
@@ -1428,13 +1502,14 @@ int conv_impl(const T *x, double *out, double *grad, float *outf, const int8_t *
             a.conv_width = conv_width; a.scaling_type = scaling_type;
             a.MW = masks_per_diag(R); a.nb = (int)((num_freqs + 1023) / 1024);
             a.scale = sqrt(1.0 / (double)num_freqs);
+            if (mode == MODE_CONV_GRAD) { a.grad = grad; a.sigma = sigma; }
             const int lg = ilog2(P);
             fill_norms(a, lg);
             rc = pack_masks(radem, (uint64_t *)workspace, R, a.MW, st);
             if (rc) return rc;
             const long nblocks = (n * a.nb + 3) / 4;
             if (nblocks > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
-            if (mode == MODE_CONV) {
+            if (mode != MODE_MAXPOOL) {
 #define CALL_CONV(LG) hipLaunchKernelGGL((wave_conv_kernel<LG, false>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
                 DISPATCH_LOG2P(lg, CALL_CONV)
 #undef CALL_CONV
@@ -1630,7 +1705,7 @@ int zcache_build_impl(const float *x, float *zc, const int8_t *radem, const floa
     if (rc) return rc;
     const long nblocks = (n * a.nb + 3) / 4;
     if (nblocks > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
-#define CALL_RBFC(LG) hipLaunchKernelGGL((wave_rbf_kernel<LG, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
+#define CALL_RBFC(LG) hipLaunchKernelGGL((wave_rbf_kernel<LG, OUT_CACHE>), dim3((unsigned)nblocks), dim3(256), 0, st, a)
     DISPATCH_LOG2P(lg, CALL_RBFC)
 #undef CALL_RBFC
     HIP_TRY(hipGetLastError(), "wave_rbf_kernel (cache) launch");
