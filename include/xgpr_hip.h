@@ -205,6 +205,19 @@ int xgpr_zcache_matvec_f32(const float *zc, const double *v, double *w_out, long
 int xgpr_zcache_matvec_scaled_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs,
                                   double scale, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Block matvec over the resident cache for k right-hand sides, the matrix-core part of the
+ * CG path: replaces `matvec += Z.T @ (Z @ vec)` of GPU_ConjugateGrad._matvec for vec of shape
+ * [M, k] (fitting_toolkit/cg_tools.py:41-44; k = nsamples + 1 = 26 in approximate_nmll,
+ * xgp_regression.py:338-367).  v, w_out: float64 [num_rffs, k] C-contiguous; zc as above.
+ * w_out (+)= scale^2 * Zc^T (Zc v) with Z[:,0] = 1 under fit_intercept, float64 MFMA
+ * (v_mfma_f64_16x16x4_f64), deterministic.  scale <= 0 selects the RBF-family scale
+ * sqrt(1/F) or sqrt(1/(F - 0.5)) (rbf_ops.cpp:68-72); accumulate != 0 adds into w_out.
+ * 1 <= k <= 32 per call, num_rffs a multiple of 4. */
+size_t xgpr_zcache_block_workspace_bytes(long n, long num_rffs, long k);
+int xgpr_zcache_block_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs,
+                                 long k, int fit_intercept, double scale, int accumulate,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- self test of the cross-lane butterfly stages the wave-level FHT is built on: for each
  * of the 6 lane strides h = 1, 2, 4, 8, 16, 32 runs one stage on v[r] = lane + 64 r
  * (r = 0..15) and writes the result to out[6][16][64] (int32, device).  Expected:

@@ -365,6 +365,24 @@ class OracleKernel:
             out[:, 0] = 1.
         return out
 
+    def gradient_x(self, input_x, sequence_length=None):
+        """kernels/kernel_baseclass.py:328-361 with sorf_kernel_baseclass.py:136-162 /
+        conv_kernel_baseclass.py:157-190: unscaled float32 input, sigma passed to the operator."""
+        xin = np.ascontiguousarray(input_x.astype(np.float32, copy=True))
+        out = np.zeros((xin.shape[0], self.num_rffs), np.float64)
+        grad = np.zeros((xin.shape[0], self.num_rffs, 1), np.float64)
+        if self.conv:
+            slen = sequence_length.astype(np.int32, copy=False)
+            self.ops.cpuConvGrad(xin, out, self.radem_diag, self.chi_arr, slen, grad,
+                                 self.hyperparams[1], self.conv_width, self.scaling_type)
+        else:
+            self.ops.cpuRBFGrad(xin, out, grad, self.radem_diag, self.chi_arr,
+                                self.hyperparams[1], self.fit_intercept)
+        if self.fit_intercept:
+            out[:, 0] = 1.
+            grad[:, 0, :] = 0.
+        return out, grad
+
 
 class OracleDataset:
     """In-memory chunk generator: data_handling/online_data_handling.py:54-94
@@ -415,7 +433,7 @@ def matvec(dataset, kernel, vec, out):
     out += kernel.get_lambda() ** 2 * vec
 
 
-def cg_fit(dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, trace=None):
+def cg_fit(dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, trace=None, nmll_settings=False):
     """fitting_toolkit/cg_tools.py:203-302 (CPU_ConjugateGrad.fit, nmll_settings=False).
     Mirrors the lagging ``err`` (computed from the *current* column after the
     next one has been written, :265).  ``trace`` (a dict) receives per-iteration
@@ -427,7 +445,7 @@ def cg_fit(dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, trace=
     z_k = np.zeros((m, 2, k))
     p_k = np.zeros((m, 2, k))
     alpha, beta = np.zeros(k), np.zeros(k)
-    losses = []
+    losses, alphas, betas = [], [], []
     x_k = np.zeros((m, k))
     w = x_k.copy()
     if preconditioner is None:
@@ -452,6 +470,8 @@ def cg_fit(dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, trace=
             (resid[:, cur, :] * z_k[:, cur, :]).sum(axis=0)
         p_k[:, nxt, :] = z_k[:, nxt, :] + beta[None, :] * p_k[:, cur, :]
         losses.append(float(err[0]))
+        alphas.append(alpha.copy())
+        betas.append(beta.copy())
         if trace is not None:
             trace.setdefault("x_k", []).append(x_k.copy())
             trace.setdefault("alpha", []).append(alpha.copy())
@@ -460,6 +480,8 @@ def cg_fit(dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, trace=
         if err.max() < tol:
             converged = True
             break
+    if nmll_settings:        # cg_tools.py:296-299
+        return x_k, np.stack(alphas)[:, 1:], np.stack(betas)[:, 1:]
     if x_k.shape[1] > 1:
         return x_k, converged, niter + 1, losses
     return x_k[:, 0], converged, niter + 1, losses
@@ -574,3 +596,140 @@ class OracleRandNysPreconditioner:
 
     def get_yty(self):
         return float(self.y_trans_y)
+
+    def get_logdet(self):
+        """preconditioners/rand_nys_preconditioners.py:96-102."""
+        logdet = 1 + (self.eig - self.prefactor) / self.prefactor
+        return float(np.log(logdet.clip(min=1e-12)).sum())
+
+    def matvec_for_sampling(self, xvec):
+        """preconditioners/rand_nys_preconditioners.py:105-119."""
+        eigvals = np.sqrt(self.eig.clip(min=0))
+        prefactor = np.sqrt(1 / self.prefactor)
+        xprod = self.u_mat.T @ xvec
+        xprod1 = self.u_mat @ (eigvals[:, None] * prefactor * xprod)
+        xprod2 = xvec - (self.u_mat @ xprod)
+        return xprod1 + xprod2
+
+
+# ---------------------------------------------------------------------------------------
+# NMLL: exact, gradient, approximate (stochastic Lanczos quadrature)
+# ---------------------------------------------------------------------------------------
+def optimize_alpha_beta(lambda_, nll_terms, ndatapoints, nrffs, beta_max=10., beta_min=0.1):
+    """scoring_toolkit/alpha_beta_optimizer.py:13-39."""
+    beta = np.sqrt(2 * nll_terms[0] / (ndatapoints * lambda_ ** 2))
+    beta = max(min(beta, beta_max), beta_min)
+    score = nll_terms[0] / (beta * lambda_) ** 2 + (ndatapoints - nrffs) * np.log(lambda_)
+    score += nll_terms[1] + ndatapoints * np.log(beta)
+    return score + 0.5 * ndatapoints * np.log(2 * np.pi), beta
+
+
+def generate_normal_probes(nsamples, num_rffs, random_seed=123, preconditioner=None):
+    """scoring_toolkit/probe_generators.py:54-75."""
+    rng = np.random.default_rng(random_seed)
+    probes = rng.standard_normal(size=(num_rffs, nsamples))
+    if preconditioner is not None:
+        probes = preconditioner.matvec_for_sampling(probes)
+    return probes
+
+
+def estimate_logdet(alphas, betas, num_rffs, preconditioner=None):
+    """scoring_toolkit/approximate_nmll_calcs.py:12-50."""
+    from scipy.linalg import eigh_tridiagonal
+    mat_diag = 1 / alphas
+    mat_diag[1:, :] += betas[:-1, :] / alphas[:-1, :]
+    upper_diag = np.sqrt(betas) / alphas
+    logdets = np.zeros((mat_diag.shape[1]))
+    for i in range(mat_diag.shape[1]):
+        eigvals, eigvecs = eigh_tridiagonal(mat_diag[:, i], upper_diag[:-1, i], lapack_driver="stev")
+        weights = eigvecs[0, :] ** 2
+        logdets[i] += (weights * np.log(eigvals)).sum()
+    logdets = num_rffs * logdets.sum() / alphas.shape[1]
+    if preconditioner is not None:
+        logdets += preconditioner.get_logdet()
+    return float(logdets)
+
+
+def approximate_nmll(kernel, dataset, preconditioner, nsamples=25, nmll_iter=500, nmll_tol=1e-6,
+                     random_seed=123, details=None):
+    """xgp_regression.py:338-367 (the preconditioner is the caller's)."""
+    m = kernel.get_num_rffs()
+    n = dataset.get_ndatapoints()
+    resid = np.zeros((m, 2, nsamples + 1))
+    probes = generate_normal_probes(nsamples, m, random_seed, preconditioner)
+    zty, yty = preconditioner.get_zty(), preconditioner.get_yty()
+    resid[:, 0, 0] = zty / n
+    resid[:, 0, 1:] = probes
+    x_k, alphas, betas = cg_fit(dataset, kernel, preconditioner, resid, nmll_iter, nmll_tol, nmll_settings=True)
+    x_k[:, 0] *= n
+    logdet = estimate_logdet(alphas, betas, m, preconditioner)
+    nll1 = float(0.5 * (yty - zty.T @ x_k[:, 0]))
+    negloglik, _ = optimize_alpha_beta(kernel.get_lambda(), np.array([nll1, 0.5 * logdet]), n, m)
+    if details is not None:
+        details.update(alphas=alphas, betas=betas, logdet=logdet, weights=x_k[:, 0], probes=probes)
+    return float(negloglik)
+
+
+def exact_nmll(kernel, dataset):
+    """xgp_regression.py:152-205 with scoring_toolkit/exact_nmll_calcs.py:42-110."""
+    from scipy.linalg import cho_solve
+    m = kernel.get_num_rffs()
+    ztz, zty, yty = np.zeros((m, m)), np.zeros(m), 0.0
+    for xin, yin, ldata in dataset.get_chunked_data():
+        z = kernel.transform_x(xin, ldata)
+        zty += z.T @ yin
+        ztz += z.T @ z
+        yty += float(yin.T @ yin)
+    ztz.flat[::m + 1] += kernel.get_lambda() ** 2
+    chol = np.linalg.cholesky(ztz)
+    weights = cho_solve((chol, True), zty)
+    nll1 = float(0.5 * (yty - zty.T @ weights))
+    nll2 = float(np.log(np.diag(chol)).sum())
+    negloglik, _ = optimize_alpha_beta(kernel.get_lambda(), np.array([nll1, nll2]), dataset.get_ndatapoints(), m)
+    return float(negloglik)
+
+
+def exact_nmll_gradient(kernel, dataset):
+    """xgp_regression.py:209-260 with scoring_toolkit/nmll_gradient_tools.py:12-162 (subsample = 1).
+    ``kernel.gradient_x`` supplies (Z, dZ/dsigma) (kernels/kernel_baseclass.py:328-361)."""
+    from scipy.linalg import cho_solve, solve_triangular
+    m = kernel.get_num_rffs()
+    hparams = np.asarray(kernel.hyperparams, dtype=np.float64)
+    nk = hparams.shape[0] - 1
+    ztz, zty, yty = np.zeros((m, m)), np.zeros(m), 0.0
+    dzty, inner = np.zeros((m, nk)), np.zeros((m, m, nk))
+    n = 0
+    for xin, yin, ldata in dataset.get_chunked_data():
+        z, dz = kernel.gradient_x(xin, ldata)
+        zty += z.T @ yin
+        ztz += z.T @ z
+        yty += float(yin.T @ yin)
+        n += z.shape[0]
+        for i in range(nk):
+            dzty[:, i] += dz[:, :, i].T @ yin
+            inner[:, :, i] += dz[:, :, i].T @ z
+    inner += np.transpose(inner, (1, 0, 2))
+    lam = hparams[0]
+    ztz.flat[::m + 1] += lam ** 2
+    chol = np.linalg.cholesky(ztz)
+    weights = cho_solve((chol, True), zty)
+    chol_inv = solve_triangular(chol, np.eye(m), lower=True)
+    nll1 = float(0.5 * (yty - zty.T @ weights))
+    nll2 = float(np.log(np.diag(chol)).sum())
+    negloglik, beta = optimize_alpha_beta(lam, np.array([nll1, nll2]), float(n), float(m))
+    grad = np.zeros(hparams.shape[0])
+    alpha = lam * beta
+    g0 = (1 / (beta ** 2 * lam ** 3)) * ((zty.T @ weights) - yty)
+    g0 += (1 / (beta ** 2 * lam)) * (weights.T @ weights)
+    g0 += (n - m) / lam
+    g0 += lam * (chol_inv ** 2).sum()
+    grad[0] = float(g0)
+    for i in range(nk):
+        trace_term = cho_solve((chol, True), inner[:, :, i])
+        g = -2 * (weights.T @ dzty[:, i])
+        g += weights.T @ (inner[:, :, i] @ weights)
+        g *= 0.5 / alpha ** 2
+        g += 0.5 * trace_term.trace()
+        grad[i + 1] = float(g)
+    grad *= hparams
+    return float(negloglik), grad

@@ -382,6 +382,51 @@ def g9_exact(xgpr):
          xtest=xte, preds=preds, pred_var=var)
 
 
+def g10_nmll(xgpr):
+    """Exact NMLL, its gradient and the approximate (SLQ) NMLL on the reference fixture
+    (tests/approximate_nmll_tests/test_slq_nmll.py:18-21 hyperparameters, 512 RFFs here):
+    xgp_regression.py:152-260 (exact), :264-367 (approximate) with the intermediate CG
+    coefficients of scoring_toolkit/approximate_nmll_calcs.py:12-50 recorded."""
+    from xGPR import xGPRegression
+    from xGPR.data_handling.dataset_builder import build_regression_dataset
+    from xGPR.preconditioners.rand_nys_preconditioners import RandNysPreconditioner
+    from xGPR.fitting_toolkit.cg_tools import CPU_ConjugateGrad
+    from xGPR.scoring_toolkit.probe_generators import generate_normal_probes_cpu
+    from xGPR.scoring_toolkit.approximate_nmll_calcs import estimate_logdet
+    xtr = np.load(os.path.join(REF_TESTDATA, "0_block_trainxvalues.npy"))
+    ytr = np.load(os.path.join(REF_TESTDATA, "0_block_trainyvalues.npy"))
+    ds = build_regression_dataset(xtr, ytr, chunk_size=2000)
+    out = {}
+    settings = {"max_rank": 64, "preconditioner_mode": "srht_2", "nsamples": 25, "nmll_iter": 500,
+                "nmll_tol": 1e-6}
+    for tag, hparam in (("easy", np.array([0., 1.0])), ("hard", np.array([np.log(1e-3), 1.0]))):
+        mod = xGPRegression(num_rffs=512, kernel_choice="RBF", variance_rffs=12, random_seed=123,
+                            device="cpu", kernel_settings={"intercept": True})
+        out[f"{tag}_hparam_log"] = hparam
+        out[f"{tag}_exact_nmll"] = np.float64(mod.exact_nmll(hparam, ds))
+        nll, grad = mod.exact_nmll_gradient(hparam, ds)
+        out[f"{tag}_grad_nmll"] = np.float64(nll)
+        out[f"{tag}_grad"] = np.asarray(grad)
+        out[f"{tag}_approx_nmll"] = np.float64(mod.approximate_nmll(hparam, ds, manual_settings=dict(settings)))
+        # the same computation step by step, to record what the test double must reproduce
+        kernel = mod.kernel
+        kernel.set_hyperparams(hparam, logspace=True)
+        pre = RandNysPreconditioner(kernel, ds, settings["max_rank"], False, 123, settings["preconditioner_mode"])
+        probes = generate_normal_probes_cpu(settings["nsamples"], kernel.get_num_rffs(), 123, pre)
+        resid = np.zeros((kernel.get_num_rffs(), 2, settings["nsamples"] + 1))
+        resid[:, 0, 0] = pre.get_zty() / ds.get_ndatapoints()
+        resid[:, 0, 1:] = probes
+        x_k, alphas, betas = CPU_ConjugateGrad().fit(ds, kernel, pre, resid, settings["nmll_iter"],
+                                                     settings["nmll_tol"], verbose=False, nmll_settings=True)
+        out[f"{tag}_probes"] = probes
+        out[f"{tag}_alphas"] = alphas
+        out[f"{tag}_betas"] = betas
+        out[f"{tag}_xk0"] = x_k[:, 0] * ds.get_ndatapoints()
+        out[f"{tag}_precond_logdet"] = np.float64(pre.get_logdet())
+        out[f"{tag}_logdet"] = np.float64(estimate_logdet(alphas, betas, kernel.get_num_rffs(), pre, "cpu"))
+    save("g10_nmll.npz", **out)
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -393,3 +438,4 @@ if __name__ == "__main__":
     g7_cg(xgpr)
     g8_e2e(xgpr)
     g9_exact(xgpr)
+    g10_nmll(xgpr)

@@ -1,0 +1,175 @@
+"""GPU parity of the "next" rows 1-2 of SURVEY.md section 8f: the block (k right-hand sides) CG
+matvec on the float64 matrix cores, the approximate NMLL built on it, and the exact NMLL with its
+gradient -- against the oracle and against values the REFERENCE's own Python produced
+(tests/golden/g10_nmll.npz, reference xgp_regression.py:152-367).  Tolerances: 1e-5 relative
+(BASELINE.json north_star); the contraction itself is held to 1e-12 against a float64 product over
+the same cached features."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("n,d,m,k,icpt", [(700, 20, 256, 5, True), (257, 33, 2100, 26, False),
+                                          (1, 8, 64, 1, True), (15, 8, 4, 3, True), (513, 64, 1024, 40, True),
+                                          (600, 16, 36, 32, False), (2000, 32, 512, 26, True)])
+def test_block_matvec_vs_oracle(oracle, n, d, m, k, icpt):
+    """hipZCacheBlockMatvec over a cache built by hipRBFFeatureCache == the oracle's
+    Z^T (Z V) (reference cg_tools.py:189-191 with V of k columns), ragged sizes included."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel, scale_input, block_workspace_bytes
+    rng = np.random.default_rng(n + m + k)
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    hp = np.array([0.3, 0.8])
+    v = rng.standard_normal((m, k))
+    kern = make_kernel("RBF", x.shape, m, 123, DEV, {"intercept": icpt})
+    kern.set_hyperparams(hp, logspace=False)
+    xs = scale_input(torch.from_numpy(x).to(DEV), hp[1])
+    zc = torch.empty((n, m), dtype=torch.float32, device=DEV)
+    kern.fill_feature_cache(xs, zc)
+    vd = torch.from_numpy(v).to(DEV)
+    out = torch.full((m, k), 7.0, dtype=torch.float64, device=DEV)
+    ws = torch.empty(block_workspace_bytes(n, m, k), dtype=torch.uint8, device=DEV)
+    kern.ztz_block_cached(zc, vd, out, ws)
+    okern = orc.OracleKernel("RBF", m, x.shape, hp, 123, fit_intercept=icpt, ops=oracle)
+    z = okern.transform_x(x.astype(np.float64))
+    ref = z.T @ (z @ v)
+    assert rel(out, ref) < 1e-6        # the float32 features themselves agree to ~4e-7 of their scale
+    # the contraction alone: float64 torch product over the very same cached float32 features
+    scale = float(np.float32(np.sqrt(1.0 / (m // 2 - 0.5 if icpt else m // 2))))
+    zd = zc.double() * scale
+    if icpt:
+        zd[:, 0] = 1.0
+    ref_same = (zd.T @ (zd @ vd)).cpu().numpy()
+    assert rel(out, ref_same) < 1e-12
+    # accumulate: a second call adds the same product
+    kern.ztz_block_cached(zc, vd, out, ws, accumulate=True)
+    assert rel(out, 2 * ref_same) < 1e-12
+    # deterministic
+    out2 = torch.empty_like(out)
+    kern.ztz_block_cached(zc, vd, out2, ws)
+    kern.ztz_block_cached(zc, vd, out, ws)
+    assert torch.equal(out, out2)
+
+
+def test_block_matvec_rejects_bad_arguments():
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    zc = torch.zeros((8, 6), dtype=torch.float32, device=DEV)       # num_rffs not a multiple of 4
+    v = torch.zeros((6, 2), dtype=torch.float64, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError):
+        ext.hipZCacheBlockMatvec(zc, v, torch.empty_like(v), True, ws)
+    zc = torch.zeros((8, 8), dtype=torch.float32, device=DEV)
+    v = torch.zeros((8, 33), dtype=torch.float64, device=DEV)       # more than 32 columns per call
+    with pytest.raises(RuntimeError):
+        ext.hipZCacheBlockMatvec(zc, v, torch.empty_like(v), True, ws)
+    v = torch.zeros((8, 4), dtype=torch.float64, device=DEV)
+    with pytest.raises(RuntimeError):                               # workspace too small
+        ext.hipZCacheBlockMatvec(zc, v, torch.empty_like(v), True, ws[:16])
+    with pytest.raises(TypeError):                                  # float32 right-hand sides
+        ext.hipZCacheBlockMatvec(zc, v.float(), torch.empty_like(v), True, ws)
+
+
+def test_block_cg_conv_kernel_matches_oracle(oracle):
+    """Batched right-hand sides with a convolution kernel: per-chunk float32 feature rows through the
+    block matvec (scale 1) vs the oracle's batched CG."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import ConjugateGrad
+    rng = np.random.default_rng(15)
+    n, L, C, m, k = 300, 20, 6, 128, 4
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(5, L + 1, size=n).astype(np.int32)
+    y = rng.standard_normal(n)
+    hp = np.array([0.6, 0.7])
+    rhs = rng.standard_normal((m, k))
+    for cache in (False, True):
+        ds = build_regression_dataset(x, y, sl, chunk_size=100, device=DEV)
+        kern = make_kernel("Conv1dRBF", x.shape, m, 123, DEV, {"conv_width": 5, "averaging": "full"})
+        kern.set_hyperparams(hp, logspace=False)
+        resid = torch.zeros((m, 2, k), dtype=torch.float64, device=DEV)
+        resid[:, 0, :] = torch.from_numpy(rhs).to(DEV)
+        xk, conv, niter, _ = ConjugateGrad(cache_features=cache).fit(ds, kern, None, resid, 300, 1e-9, False)
+        ods = orc.OracleDataset(x.astype(np.float64), y, sl, chunk_size=100)
+        okern = orc.OracleKernel("Conv1dRBF", m, x.shape, hp, 123, conv_width=5, averaging="full", ops=oracle)
+        oresid = np.zeros((m, 2, k))
+        oresid[:, 0, :] = rhs
+        xref, oconv, oniter, _ = orc.cg_fit(ods, okern, None, oresid, 300, 1e-9)
+        assert conv and oconv and abs(niter - oniter) <= 1
+        assert rel(xk, xref) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["easy", "hard"])
+def test_g10_nmll_vs_reference(tag):
+    """exact_nmll, exact_nmll_gradient and approximate_nmll on the reference fixture against the
+    reference's own numbers; the 26-column solve runs on the block matvec (regenerating windows and
+    resident cache both)."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd import nmll
+    g8, g = load_golden("g8_e2e.npz"), load_golden("g10_nmll.npz")
+    x, y = g8["xtrain"], g8["ytrain"]
+    ds = build_regression_dataset(x, y, chunk_size=2000, device=DEV)
+    kern = make_kernel("RBF", x.shape, 512, 123, DEV, {"intercept": True})
+    kern.set_hyperparams(g[f"{tag}_hparam_log"], logspace=True)
+    exact = float(g[f"{tag}_exact_nmll"])
+    assert np.isclose(nmll.exact_nmll(kern, ds), exact, rtol=1e-6)
+    nll, grad = nmll.exact_nmll_gradient(kern, ds)
+    assert np.isclose(nll, float(g[f"{tag}_grad_nmll"]), rtol=1e-6)
+    assert np.allclose(grad, g[f"{tag}_grad"], rtol=2e-4, atol=1e-4)
+    pre = RandNysPreconditioner(kern, ds, 64, False, 123, "srht_2")
+    assert np.isclose(pre.get_logdet(), float(g[f"{tag}_precond_logdet"]), rtol=1e-6)
+    settings = {"nsamples": 25, "nmll_iter": 500, "nmll_tol": 1e-6}
+    for cache in (False, True):
+        det = {}
+        approx = nmll.approximate_nmll(kern, ds, pre, settings, 123, cache_features=cache, details=det)
+        assert rel(det["probes"], g[f"{tag}_probes"]) < 1e-6
+        na = g[f"{tag}_alphas"].shape[0]
+        assert abs(det["niter"] - na) <= 1
+        nc = min(na, det["niter"], 8)
+        assert np.allclose(det["alphas"].cpu().numpy()[:nc], g[f"{tag}_alphas"][:nc], rtol=1e-5)
+        assert np.allclose(det["betas"].cpu().numpy()[:nc], g[f"{tag}_betas"][:nc], rtol=1e-5, atol=1e-12)
+        assert rel(det["weights"], g[f"{tag}_xk0"]) < 1e-5
+        assert np.isclose(det["logdet"], float(g[f"{tag}_logdet"]), rtol=1e-5)
+        assert np.isclose(approx, float(g[f"{tag}_approx_nmll"]), rtol=1e-6)
+        assert 100 * abs(approx - exact) / exact < 1.0     # the reference's acceptance bar (test_slq_nmll.py:73-79)
+
+
+def test_nmll_gradient_matches_finite_difference_of_exact_nmll():
+    """Property test at a size the goldens do not cover (Matern, no intercept): d NMLL / d log sigma
+    from exact_nmll_gradient vs a central difference of exact_nmll."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd import nmll
+    rng = np.random.default_rng(21)
+    n, d, m = 600, 12, 128
+    x = rng.uniform(-1, 1, size=(n, d))
+    y = np.sin(x @ rng.standard_normal(d)) + 0.1 * rng.standard_normal(n)
+    ds = build_regression_dataset(x, y, chunk_size=250, device=DEV)
+    kern = make_kernel("Matern", x.shape, m, 123, DEV, {"matern_nu": 1.5, "intercept": False})
+    hp = np.array([-0.5, 0.2])
+    kern.set_hyperparams(hp, logspace=True)
+    _, grad = nmll.exact_nmll_gradient(kern, ds)
+    eps = 1e-3
+    fd = np.zeros(2)
+    for i in range(2):
+        hi, lo = hp.copy(), hp.copy()
+        hi[i] += eps
+        lo[i] -= eps
+        kern.set_hyperparams(hi, logspace=True)
+        fhi = nmll.exact_nmll(kern, ds)
+        kern.set_hyperparams(lo, logspace=True)
+        flo = nmll.exact_nmll(kern, ds)
+        fd[i] = (fhi - flo) / (2 * eps)
+    assert np.allclose(grad, fd, rtol=2e-3, atol=2e-3)

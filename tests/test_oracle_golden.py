@@ -217,3 +217,32 @@ def test_oracle_validation_errors(oracle):
         oracle.cpuFastHadamardTransform2D(np.zeros((3, 12)))
     with pytest.raises(RuntimeError):
         oracle.cpuSRHT(np.zeros((3, 16)), np.ones(8, np.int8))
+
+
+@pytest.mark.parametrize("tag", ["easy", "hard"])
+def test_g10_nmll_oracle_vs_reference(oracle, tag):
+    """Exact NMLL, its gradient and the SLQ approximation (reference xgp_regression.py:152-367) on the
+    reference fixture: the oracle's restatement against the reference's own run, including the
+    intermediate probe draws and CG coefficients of the 26-column solve."""
+    g8, g = load_golden("g8_e2e.npz"), load_golden("g10_nmll.npz")
+    x, y = g8["xtrain"], g8["ytrain"]
+    ds = orc.OracleDataset(x, y, chunk_size=2000)
+    kern = orc.OracleKernel("RBF", 512, x.shape, np.exp(g[f"{tag}_hparam_log"]), 123, ops=oracle)
+    assert np.isclose(orc.exact_nmll(kern, ds), float(g[f"{tag}_exact_nmll"]), rtol=1e-9)
+    nll, grad = orc.exact_nmll_gradient(kern, ds)
+    assert np.isclose(nll, float(g[f"{tag}_grad_nmll"]), rtol=1e-9)
+    assert np.allclose(grad, g[f"{tag}_grad"], rtol=1e-6, atol=1e-8)
+    pre = orc.OracleRandNysPreconditioner(kern, ds, 64, 123, "srht_2")
+    assert np.isclose(pre.get_logdet(), float(g[f"{tag}_precond_logdet"]), rtol=1e-8)
+    det = {}
+    approx = orc.approximate_nmll(kern, ds, pre, 25, 500, 1e-6, 123, details=det)
+    assert np.allclose(det["probes"], g[f"{tag}_probes"], rtol=1e-8, atol=1e-10)
+    na = g[f"{tag}_alphas"].shape[0]
+    assert abs(det["alphas"].shape[0] - na) <= 1
+    nc = min(na, det["alphas"].shape[0], 10)
+    assert np.allclose(det["alphas"][:nc], g[f"{tag}_alphas"][:nc], rtol=1e-6)
+    assert np.allclose(det["betas"][:nc], g[f"{tag}_betas"][:nc], rtol=1e-6)
+    assert np.isclose(det["logdet"], float(g[f"{tag}_logdet"]), rtol=1e-6)
+    assert np.isclose(approx, float(g[f"{tag}_approx_nmll"]), rtol=1e-7)
+    # the reference's own acceptance test: approximate within 1 % of exact (test_slq_nmll.py:73-79)
+    assert 100 * abs(approx - float(g[f"{tag}_exact_nmll"])) / float(g[f"{tag}_exact_nmll"]) < 1.0

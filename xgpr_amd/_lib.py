@@ -39,6 +39,7 @@ SIGNATURES = {
     "xgpr_rbf_feature_cache_f32": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _vp, _sz, _vp],
     "xgpr_zcache_matvec_f32": [_vp, _vp, _vp, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_zcache_matvec_scaled_f32": [_vp, _vp, _vp, _l, _l, _d, _vp, _sz, _vp],
+    "xgpr_zcache_block_matvec_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _i, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
 }
 SIZE_FUNCS = {
@@ -46,6 +47,7 @@ SIZE_FUNCS = {
     "xgpr_sorf_workspace_bytes": [_l, _l, _i],
     "xgpr_precond_apply_workspace_bytes": [_l],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
+    "xgpr_zcache_block_workspace_bytes": [_l, _l, _l],
 }
 STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch"]
 

@@ -50,24 +50,67 @@ class ConjugateGrad:
         self.comm = comm
         self.cache_features = cache_features
         self._ws = None
+        self._bws = None
+        self._zwin = None
 
     def _matvec(self, dataset, kernel, vec, matvec):
         """cg_tools.py:173-200 (regression branch): matvec <- (Z^T Z + lambda^2) vec."""
         matvec.zero_()
         # k <= 2 right-hand sides: one fused pass per column (Z never written).  More columns (the
-        # NMLL probes, k = 26): generate each chunk of Z once and let the two block GEMMs
-        # [n x M][M x k], [M x n][n x k] run on the matrix cores (library float64 MFMA GEMM).
+        # NMLL probes, k = 26): the two contractions [n x M][M x k], [M x n][n x k] run on the
+        # float64 matrix cores over float32 feature rows -- the resident cache, or windows of rows
+        # regenerated into scratch (hipZCacheBlockMatvec).
         if kernel.fused_ok() and vec.shape[1] <= 2:
             xs = dataset.scaled_x(kernel.hyperparams[1])
             if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != xs.device:
                 self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=xs.device)
             self._matvec_cols(kernel, xs, vec, matvec)
+        elif vec.is_cuda and hasattr(kernel, "block_ok") and kernel.block_ok():
+            self._matvec_block(dataset, kernel, vec, matvec)
         else:
             for x, lengths in dataset.get_chunked_x_data():
                 z = kernel.transform_x(x, lengths)
                 matvec += z.T @ (z @ vec)
         self.comm.all_reduce_(matvec)
         matvec += kernel.get_lambda() ** 2 * vec
+
+    BLOCK_WINDOW_BYTES = 2 << 30        # scratch for regenerated float32 feature rows
+
+    def _block_ws(self, nrows, kernel, k, dev):
+        from .kernels import block_workspace_bytes
+        need = block_workspace_bytes(nrows, kernel.get_num_rffs(), k)
+        if self._bws is None or self._bws.numel() < need or self._bws.device != dev:
+            self._bws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._bws
+
+    def _matvec_block(self, dataset, kernel, vec, matvec):
+        """matvec += Z^T (Z vec) for a block of right-hand sides (matvec is zero on entry)."""
+        m, k = vec.shape
+        if not vec.is_contiguous():
+            vec = vec.contiguous()
+        out = matvec if matvec.is_contiguous() else torch.zeros_like(vec)
+        if self.cache_features and dataset.get_local_ndatapoints() > 0:
+            zc = dataset.feature_cache(kernel)
+            kernel.ztz_block_cached(zc, vec, out, self._block_ws(zc.shape[0], kernel, k, vec.device))
+        elif kernel.fused_ok():
+            xs = dataset.scaled_x(kernel.hyperparams[1])
+            n = xs.shape[0]
+            win = max(1024, min(n, self.BLOCK_WINDOW_BYTES // (4 * m)))
+            if self._zwin is None or self._zwin.shape != (win, m) or self._zwin.device != vec.device:
+                self._zwin = torch.empty((win, m), dtype=torch.float32, device=vec.device)
+            ws = self._block_ws(win, kernel, k, vec.device)
+            for lo in range(0, n, win):
+                hi = min(n, lo + win)
+                zc = self._zwin[:hi - lo]
+                kernel.fill_feature_cache(xs[lo:hi], zc)
+                kernel.ztz_block_cached(zc, vec, out, ws, accumulate=True)
+        else:
+            for x, lengths in dataset.get_chunked_x_data():
+                zc = kernel.transform_x(x, lengths).to(torch.float32)
+                kernel.ztz_block_cached(zc, vec, out, self._block_ws(zc.shape[0], kernel, k, vec.device),
+                                        accumulate=True)
+        if out is not matvec:
+            matvec.copy_(out)
 
     def _matvec_cols(self, kernel, xs, vec, matvec):
         tmp = torch.empty(vec.shape[0], dtype=torch.float64, device=vec.device)
@@ -238,12 +281,14 @@ class ConjugateGrad:
         return x_k[:, 0], converged, niter + 1, losses
 
 
-def _resolve_cache_mode(cache_features, kernel, dataset):
+def _resolve_cache_mode(cache_features, kernel, dataset, block=False):
     """"auto": keep Z resident when the kernel supports it and the float32 cache of this shard fits
-    comfortably in free HBM (it then needs cache + 2 GB with 1.5x headroom)."""
+    comfortably in free HBM (it then needs cache + 2 GB with 1.5x headroom).  ``block``: the solve has
+    a block of right-hand sides (matrix-core matvec), which caches under ``block_ok``."""
     if cache_features != "auto":
         return bool(cache_features)
-    if not (hasattr(kernel, "cache_ok") and kernel.cache_ok()) or torch.device(kernel.device).type != "cuda":
+    supported = getattr(kernel, "block_ok" if block else "cache_ok", None)
+    if supported is None or not supported() or torch.device(kernel.device).type != "cuda":
         return False
     free, _total = torch.cuda.mem_get_info(torch.device(kernel.device))
     return 1.5 * dataset.feature_cache_bytes(kernel) + 2e9 < free

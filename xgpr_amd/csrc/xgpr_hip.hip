@@ -1153,6 +1153,276 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double *__restr
 }
 
 // ------------------------------------------------------------------------------------
+// Block matvec over the resident feature cache for k right-hand sides (the approximate-NMLL
+// probes: k = nsamples + 1 = 26, xgp_regression.py:338-367; any batched solve):
+//     W[M, k] = s^2 * Zc^T (Zc V),  Zc = the float32 cache (exact in float64), V, W float64.
+// This is the reference's `Z.T @ (Z @ vec)` (cg_tools.py:41-44) as two dense contractions, and it
+// is the matrix-core part of the CG path: v_mfma_f64_16x16x4_f64 with float64 accumulation.
+//   zblock_t_kernel:  T[n, KP]  = Zc V         (contract features; a wave owns 64 datapoints)
+//   zblock_w_kernel:  slab[M, KP] = Zc^T T     (contract datapoints; a wave owns 64 features)
+// Operand maps (guide §3): A lane l -> A[i = l & 15][k = l >> 4], B lane l -> B[k = l >> 4][j = l & 15],
+// D register r -> D[i = (l >> 4) + 4 r][j = l & 15].  The contraction index of one instruction is
+// only a label, so a lane loads 16 bytes (4 consecutive features) and spends one element per
+// instruction: instruction e of a group contracts features {16 q + 4 (l >> 4) + e} (T kernel) or
+// owns output features {f0 + 4 (l & 15) + e} (W kernel); both are bijections undone at the store.
+// ------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct ZbArgs {
+    const float *zc; const double *V; double *T; double *wpart;
+    long n; long M; int k; int fit_intercept; double scale;
+    long rows_per_range;
+};
+
+constexpr int ZB_FEATS = 16;      // features per LDS chunk of V (T kernel)
+constexpr int ZB_ROWS = 32;       // datapoints per LDS chunk of T (W kernel)
+constexpr int ZB_RING = 4;        // chunks of the streamed operand per wave: ZB_RING - 1 in flight, one consumed
+constexpr int ZB_TROWS = 512;     // datapoints per workgroup of the T kernel (8 waves x 64)
+constexpr int ZB_WFEATS = 512;    // features per workgroup of the W kernel (8 waves x 64)
+
+// Both kernels: 8 waves per workgroup (the CU places a 4-wave workgroup's waves on two SIMDs, which
+// halves the matrix-pipe rate: tools/mfma_probe.hip), loads are branch-free (clamped addresses; what a
+// clamped load returns is multiplied by a zero from the other operand or never stored) so the
+// compiler can count vmcnt, and every wave keeps a ring of ZB_RING chunks of its streamed operand in
+// registers (all but one in flight) because HBM latency under load is several microseconds.
+__device__ __forceinline__ double elem(const float4 &v, int e) {
+    return (double)(e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w);
+}
+
+template <int CT>
+__global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
+    constexpr int KP = 16 * CT;
+    constexpr int VS = KP + 4;                     // +32 B per row: lane groups g and g+1 land 128 B apart
+    constexpr int QG = ZB_FEATS / 16;              // groups of 16 features per chunk
+    constexpr int VPT = (ZB_FEATS * KP + 511) / 512;   // V elements staged per thread per chunk
+    __shared__ __attribute__((aligned(16))) double vs[2][ZB_FEATS * VS];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long rbase = (long)blockIdx.x * ZB_TROWS + 64 * w;
+    const float *rp[4];
+    #pragma unroll
+    for (int rt = 0; rt < 4; rt++) {
+        long row = rbase + 16 * rt + c;
+        if (row >= a.n) row = a.n - 1;             // clamped rows are computed and never stored
+        rp[rt] = a.zc + row * a.M + 4 * g;
+    }
+    double4_t acc[4][CT];
+    #pragma unroll
+    for (int rt = 0; rt < 4; rt++)
+        #pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[rt][ct] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const long nchunks = (a.M + ZB_FEATS - 1) / ZB_FEATS;
+    const double inv_scale = 1.0 / a.scale;
+    const long fmax = a.M - 4 - 4 * g;             // last float4 of a row, relative to rp
+
+    auto load_a = [&](long ch, float4 (&dst)[QG][4]) {
+        #pragma unroll
+        for (int q = 0; q < QG; q++) {
+            long f = ch * ZB_FEATS + 16 * q;
+            if (f > fmax) f = fmax;                // past the last feature: V supplies the zeros
+            #pragma unroll
+            for (int rt = 0; rt < 4; rt++) dst[q][rt] = *reinterpret_cast<const float4 *>(rp[rt] + f);
+        }
+    };
+    auto load_v = [&](long ch, double (&dst)[VPT]) {
+        #pragma unroll
+        for (int e = 0; e < VPT; e++) {
+            const int idx = threadIdx.x + 512 * e;
+            const long f = ch * ZB_FEATS + idx / KP;
+            const int col = idx % KP;
+            const bool ok = idx < ZB_FEATS * KP && f < a.M && col < a.k;
+            const double v = a.V[ok ? f * a.k + col : 0];
+            dst[e] = ok ? v : 0.0;
+        }
+    };
+    auto store_v = [&](int buf, const double (&src)[VPT]) {
+        #pragma unroll
+        for (int e = 0; e < VPT; e++) {
+            const int idx = threadIdx.x + 512 * e;
+            if (idx < ZB_FEATS * KP) vs[buf][(idx / KP) * VS + idx % KP] = src[e];
+        }
+    };
+    auto compute = [&](long ch, const float4 (&cur)[QG][4]) {
+        const bool first = a.fit_intercept && ch == 0 && g == 0;
+        const double *vb = vs[ch & 1];
+        #pragma unroll
+        for (int q = 0; q < QG; q++) {
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                double b[CT];
+                #pragma unroll
+                for (int ct = 0; ct < CT; ct++) b[ct] = vb[(16 * q + 4 * g + e) * VS + 16 * ct + c];
+                #pragma unroll
+                for (int rt = 0; rt < 4; rt++) {
+                    double av = elem(cur[q][rt], e);
+                    if (q == 0 && e == 0 && first) av = inv_scale;     // Z[:, 0] = 1 (kernel_baseclass.py:296-297)
+                    #pragma unroll
+                    for (int ct = 0; ct < CT; ct++)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[ct], acc[rt][ct], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the conversions of later groups out of this one's registers
+            }
+        }
+    };
+
+    static_assert(ZB_RING == 4, "the stage loop below is unrolled for a ring of 4");
+    float4 ring[ZB_RING][QG][4];
+    double vreg[ZB_RING][VPT];
+    #pragma unroll
+    for (int i = 0; i < ZB_RING - 1; i++) { load_v(i, vreg[i]); load_a(i, ring[i]); }
+    store_v(0, vreg[0]);
+    __syncthreads();
+#define ZB_STAGE(S, CH)                                                                                       \
+    {                                                                                                         \
+        load_v((CH) + 3, vreg[((S) + 3) % 4]); load_a((CH) + 3, ring[((S) + 3) % 4]);                         \
+        compute((CH), ring[(S)]);                                                                             \
+        store_v((int)(((CH) + 1) & 1), vreg[((S) + 1) % 4]);                                                  \
+        __syncthreads();                                                                                      \
+    }
+    for (long ch = 0; ch < nchunks; ch += 4) {
+        ZB_STAGE(0, ch)                // chunks past the last one multiply clamped loads by zeros
+        ZB_STAGE(1, ch + 1)
+        ZB_STAGE(2, ch + 2)
+        ZB_STAGE(3, ch + 3)
+    }
+#undef ZB_STAGE
+    #pragma unroll
+    for (int rt = 0; rt < 4; rt++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long row = rbase + 16 * rt + g + 4 * r;
+            if (row < a.n) {
+                #pragma unroll
+                for (int ct = 0; ct < CT; ct++) a.T[row * KP + 16 * ct + c] = acc[rt][ct][r];
+            }
+        }
+}
+
+template <int CT>
+__global__ __launch_bounds__(512, 1) void zblock_w_kernel(ZbArgs a) {
+    constexpr int KP = 16 * CT;
+    constexpr int TS = KP + 4;
+    constexpr int STEPS = ZB_ROWS / 4;
+    constexpr int TPT = (ZB_ROWS * KP + 511) / 512;  // T elements staged per thread per chunk
+    __shared__ __attribute__((aligned(16))) double ts[2][ZB_ROWS * TS];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long fw = (long)blockIdx.x * ZB_WFEATS + 64 * w;
+    long f0 = fw + 4 * c;                            // this lane's 4 features (the A row index)
+    const bool icpt = a.fit_intercept && f0 == 0;
+    if (f0 > a.M - 4) f0 = a.M - 4;                  // clamped features are computed and never stored
+    const long rbeg = (long)blockIdx.y * a.rows_per_range;
+    long rend = rbeg + a.rows_per_range;
+    if (rend > a.n) rend = a.n;
+    const long nchunks = (rend - rbeg + ZB_ROWS - 1) / ZB_ROWS;      // >= 1 by construction of the grid
+    const double inv_scale = 1.0 / a.scale;
+    double4_t acc[4][CT];
+    #pragma unroll
+    for (int e = 0; e < 4; e++)
+        #pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[e][ct] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const float *zf = a.zc + f0;
+
+    auto load_a = [&](long ch, float4 (&dst)[STEPS]) {
+        #pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            long row = rbeg + ch * ZB_ROWS + 4 * s + g;
+            if (row > rend - 1) row = rend - 1;      // past the range: T supplies the zeros
+            dst[s] = *reinterpret_cast<const float4 *>(zf + row * a.M);
+        }
+    };
+    auto load_t = [&](long ch, double (&dst)[TPT]) {
+        #pragma unroll
+        for (int e = 0; e < TPT; e++) {
+            const int idx = threadIdx.x + 512 * e;
+            const long row = rbeg + ch * ZB_ROWS + idx / KP;
+            const bool ok = idx < ZB_ROWS * KP && row < rend;
+            const double v = a.T[(ok ? row : rend - 1) * KP + idx % KP];
+            dst[e] = ok ? v : 0.0;
+        }
+    };
+    auto store_t = [&](int buf, const double (&src)[TPT]) {
+        #pragma unroll
+        for (int e = 0; e < TPT; e++) {
+            const int idx = threadIdx.x + 512 * e;
+            if (idx < ZB_ROWS * KP) ts[buf][(idx / KP) * TS + idx % KP] = src[e];
+        }
+    };
+    auto compute = [&](long ch, const float4 (&cur)[STEPS]) {
+        const double *tb = ts[ch & 1];
+        #pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            double b[CT];
+            #pragma unroll
+            for (int ct = 0; ct < CT; ct++) b[ct] = tb[(4 * s + g) * TS + 16 * ct + c];
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                double av = elem(cur[s], e);
+                if (e == 0 && icpt) av = inv_scale;
+                #pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+                    acc[e][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[ct], acc[e][ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // keep the conversions of later steps out of this one's registers
+        }
+    };
+
+    static_assert(ZB_RING == 4, "the stage loop below is unrolled for a ring of 4");
+    float4 ring[ZB_RING][STEPS];
+    double treg[ZB_RING][TPT];
+    #pragma unroll
+    for (int i = 0; i < ZB_RING - 1; i++) { load_t(i, treg[i]); load_a(i, ring[i]); }
+    store_t(0, treg[0]);
+    __syncthreads();
+#define ZB_STAGE(S, CH)                                                                                       \
+    {                                                                                                         \
+        load_t((CH) + 3, treg[((S) + 3) % 4]); load_a((CH) + 3, ring[((S) + 3) % 4]);                         \
+        compute((CH), ring[(S)]);                                                                             \
+        store_t((int)(((CH) + 1) & 1), treg[((S) + 1) % 4]);                                                  \
+        __syncthreads();                                                                                      \
+    }
+    for (long ch = 0; ch < nchunks; ch += 4) {
+        ZB_STAGE(0, ch)                // chunks past the last one multiply clamped loads by zeros
+        ZB_STAGE(1, ch + 1)
+        ZB_STAGE(2, ch + 2)
+        ZB_STAGE(3, ch + 3)
+    }
+#undef ZB_STAGE
+    // D register r of instruction e holds output feature fw + 4 (g + 4 r) + e, column 16 ct + c.
+    double *slab = a.wpart + (long)blockIdx.y * a.M * KP;
+    #pragma unroll
+    for (int e = 0; e < 4; e++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long f = fw + 4 * (g + 4 * r) + e;
+            if (f < a.M) {
+                #pragma unroll
+                for (int ct = 0; ct < CT; ct++) slab[f * KP + 16 * ct + c] = acc[e][ct][r];
+            }
+        }
+}
+
+// W[f, col] (+)= s2 * sum over row ranges (fixed order) of slab[range, f, col]; KP -> k compaction.
+__global__ __launch_bounds__(256) void reduce_block_slabs_kernel(const double *__restrict__ wpart, double *w_out, long M,
+                                                                 int KP, int k, long nslabs, double s2, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * KP) return;
+    const long f = idx / KP;
+    const int col = (int)(idx % KP);
+    if (col >= k) return;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    long r = 0;
+    for (; r + 3 < nslabs; r += 4) {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) s[q] += wpart[(r + q) * M * KP + idx];
+    }
+    double tail = 0.0;
+    for (; r < nslabs; r++) tail += wpart[r * M * KP + idx];
+    const double v = (((s[0] + s[1]) + (s[2] + s[3])) + tail) * s2;
+    w_out[f * k + col] = accumulate ? w_out[f * k + col] + v : v;
+}
+
+// ------------------------------------------------------------------------------------
 // CG vector updates for one right-hand side (fitting_toolkit/cg_tools.py:255-274), fused into
 // two single-workgroup kernels: M is only 10^3..10^5, so one workgroup reduces and updates the
 // whole vector in a few microseconds, deterministically, instead of ~20 library launches.
@@ -1755,6 +2025,59 @@ int zcache_matvec_impl(const float *zc, const double *vec, double *w_out, long n
     return 0;
 }
 
+struct ZbGeom { int kp; long mblk; long nrb; long rows_per_range; size_t t_bytes; size_t slab_bytes; };
+
+ZbGeom zb_geometry(long n, long num_rffs, long k) {
+    ZbGeom gm;
+    gm.kp = k <= 16 ? 16 : 32;
+    gm.mblk = (num_rffs + ZB_WFEATS - 1) / ZB_WFEATS;
+    long target = (2L * device_cus() + gm.mblk - 1) / gm.mblk;      // row ranges wanted: ~2 workgroups per CU
+    const long max_ranges = (n + ZB_ROWS - 1) / ZB_ROWS;
+    if (target > max_ranges) target = max_ranges;
+    if (target < 1) target = 1;
+    gm.rows_per_range = ((n + target - 1) / target + ZB_ROWS - 1) / ZB_ROWS * ZB_ROWS;
+    gm.nrb = (n + gm.rows_per_range - 1) / gm.rows_per_range;
+    gm.t_bytes = ((size_t)n * gm.kp * sizeof(double) + 255) / 256 * 256;
+    gm.slab_bytes = (size_t)gm.nrb * num_rffs * gm.kp * sizeof(double);
+    return gm;
+}
+
+int zcache_block_impl(const float *zc, const double *V, double *W, long n, long num_rffs, long k, int fit_intercept,
+                      double scale_override, int accumulate, void *workspace, size_t wbytes, void *stream) {
+    if (n <= 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (num_rffs < 4 || (num_rffs & 3) != 0) return fail(XGPR_ERR_UNSUPPORTED, "block matvec needs num_rffs to be a multiple of 4");
+    if (k < 1 || k > 32) return fail(XGPR_ERR_UNSUPPORTED, "block matvec takes 1..32 right-hand sides per call");
+    if (!aligned16(zc)) return fail(XGPR_ERR_WORKSPACE, "cache pointer must be 16-byte aligned");
+    const ZbGeom gm = zb_geometry(n, num_rffs, k);
+    if (!workspace || wbytes < gm.t_bytes + gm.slab_bytes || !aligned16(workspace))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_zcache_block_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    ZbArgs a = {};
+    a.zc = zc; a.V = V;
+    a.T = reinterpret_cast<double *>(workspace);
+    a.wpart = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(workspace) + gm.t_bytes);
+    a.n = n; a.M = num_rffs; a.k = (int)k; a.fit_intercept = fit_intercept;
+    a.scale = scale_override > 0.0 ? scale_override : rbf_scale<float>(num_rffs / 2, fit_intercept);
+    a.rows_per_range = gm.rows_per_range;
+    const long tblocks = (n + ZB_TROWS - 1) / ZB_TROWS;
+    if (tblocks > 2147483647L || gm.nrb > 65535) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
+    if (gm.kp == 16) {
+        hipLaunchKernelGGL(zblock_t_kernel<1>, dim3((unsigned)tblocks), dim3(512), 0, st, a);
+        HIP_TRY(hipGetLastError(), "zblock_t_kernel launch");
+        hipLaunchKernelGGL(zblock_w_kernel<1>, dim3((unsigned)gm.mblk, (unsigned)gm.nrb), dim3(512), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(zblock_t_kernel<2>, dim3((unsigned)tblocks), dim3(512), 0, st, a);
+        HIP_TRY(hipGetLastError(), "zblock_t_kernel launch");
+        hipLaunchKernelGGL(zblock_w_kernel<2>, dim3((unsigned)gm.mblk, (unsigned)gm.nrb), dim3(512), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError(), "zblock_w_kernel launch");
+    const long total = num_rffs * gm.kp;
+    hipLaunchKernelGGL(reduce_block_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.wpart, W,
+                       num_rffs, gm.kp, (int)k, gm.nrb, a.scale * a.scale, accumulate);
+    HIP_TRY(hipGetLastError(), "reduce_block_slabs_kernel launch");
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -1925,6 +2248,17 @@ int xgpr_zcache_matvec_scaled_f32(const float *zc, const double *v, double *w_ou
                                   void *workspace, size_t workspace_bytes, void *stream) {
     if (!(scale > 0.0)) return fail(XGPR_ERR_ARRAY_DIMS, "scale must be positive");
     return zcache_matvec_impl(zc, v, w_out, n, num_rffs, 0, scale, workspace, workspace_bytes, stream);
+}
+
+size_t xgpr_zcache_block_workspace_bytes(long n, long num_rffs, long k) {
+    if (n <= 0 || num_rffs <= 0 || k < 1) return 0;
+    const ZbGeom gm = zb_geometry(n, num_rffs, k > 32 ? 32 : k);
+    return gm.t_bytes + gm.slab_bytes;
+}
+int xgpr_zcache_block_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs, long k,
+                                 int fit_intercept, double scale, int accumulate, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    return zcache_block_impl(zc, v, w_out, n, num_rffs, k, fit_intercept, scale, accumulate, workspace, workspace_bytes, stream);
 }
 
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {

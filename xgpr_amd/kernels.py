@@ -82,6 +82,23 @@ class KernelBase:
             xtrans[:, 0] = 1.
         return xtrans
 
+    def gradient_x(self, input_x, sequence_length=None):
+        """kernel_baseclass.py:328-361: features and d(features)/d(sigma) from the *unscaled* input
+        (the gradient operators apply sigma themselves).  Returns float64 [n, M], [n, M, 1]."""
+        xin = self._as_device_f32(input_x).to(torch.float32, copy=True).contiguous()
+        xtrans, xgrad = self.kernel_specific_gradient(xin, sequence_length)
+        if self.fit_intercept:
+            xtrans[:, 0] = 1.
+            xgrad[:, 0, :] = 0.
+        return xtrans, xgrad
+
+    def gradient_x_y(self, input_x, input_y, sequence_length=None):
+        """kernel_baseclass.py:364-377."""
+        xtrans, dz_dsigma = self.gradient_x(input_x, sequence_length)
+        if isinstance(input_y, np.ndarray):
+            input_y = torch.from_numpy(input_y)
+        return xtrans, dz_dsigma, input_y.to(self.device, torch.float64)
+
     def transform_x_y(self, input_x, input_y, sequence_length=None):
         """kernel_baseclass.py:303-324 (regression branch)."""
         xtrans = self.transform_x(input_x, sequence_length)
@@ -116,6 +133,15 @@ class SORFKernel(KernelBase):
         ext.hipRBFFeatureGen(input_x, output_x, self.radem_diag, self.chi_arr, self.fit_intercept)
         return output_x
 
+    def kernel_specific_gradient(self, input_x, sequence_length=None):
+        """sorf_kernel_baseclass.py:136-162."""
+        n = input_x.shape[0]
+        output_x = torch.zeros((n, self.num_rffs), dtype=torch.float64, device=self.device)
+        dz_dsigma = torch.zeros((n, self.num_rffs, 1), dtype=torch.float64, device=self.device)
+        ext.hipRBFGrad(input_x, output_x, dz_dsigma, self.radem_diag, self.chi_arr,
+                       float(self.hyperparams[1]), self.fit_intercept)
+        return output_x, dz_dsigma
+
     # ---- fused per-shard reductions (what the reference does chunk by chunk with a
     # materialised Z: fitting_toolkit/cg_tools.py:189-191, scoring_toolkit/exact_nmll_calcs.py:35-37)
     supports_fused = True
@@ -141,6 +167,17 @@ class SORFKernel(KernelBase):
     def ztz_matvec_cached(self, zcache, vec, out, workspace):
         ext.hipZCacheMatvec(zcache, vec, out, self.fit_intercept, workspace)
 
+    # ---- block of right-hand sides (approximate-NMLL probes, k = 26): float64 matrix cores over
+    # the float32 cache, either the resident one or a window of rows regenerated into scratch
+    def block_ok(self):
+        return padded_dims(self._xdim[-1]) <= 1024 and self.num_rffs % 4 == 0
+
+    def fill_feature_cache(self, x_scaled, zcache):
+        ext.hipRBFFeatureCache(x_scaled, zcache, self.radem_diag, self.chi_arr)
+
+    def ztz_block_cached(self, zcache, vecs, out, workspace, accumulate=False):
+        _block_matvec(zcache, vecs, out, workspace, self.fit_intercept, 0.0, accumulate)
+
     def fused_ok(self):
         """The fused kernels cover padded width <= 1024 (single pass up to num_freqs = 8192, the
         two-pass form beyond, up to 65536)."""
@@ -148,6 +185,27 @@ class SORFKernel(KernelBase):
 
     def workspace_bytes(self):
         return ext.ztz_workspace_bytes(self.num_rffs, self.radem_diag.shape[2])
+
+
+BLOCK_COLS = 32          # right-hand sides per call of the block matvec (include/xgpr_hip.h)
+
+
+def _block_matvec(zcache, vecs, out, workspace, fit_intercept, scale, accumulate):
+    """out[M, k] (+)= Z^T (Z vecs) in column groups of BLOCK_COLS; vecs / out C-contiguous float64."""
+    k = vecs.shape[1]
+    if k <= BLOCK_COLS:
+        ext.hipZCacheBlockMatvec(zcache, vecs, out, fit_intercept, workspace, scale, accumulate)
+        return
+    for j0 in range(0, k, BLOCK_COLS):
+        j1 = min(k, j0 + BLOCK_COLS)
+        v = vecs[:, j0:j1].contiguous()
+        o = out[:, j0:j1].contiguous()
+        ext.hipZCacheBlockMatvec(zcache, v, o, fit_intercept, workspace, scale, accumulate)
+        out[:, j0:j1] = o
+
+
+def block_workspace_bytes(nrows, num_rffs, k):
+    return ext.zcache_block_workspace_bytes(nrows, num_rffs, min(k, BLOCK_COLS))
 
 
 def _rescale_chi(kernel_choice, chi_arr, random_seed, parms, obj):
@@ -229,8 +287,30 @@ class ConvSORFKernel(KernelBase):
     def ztz_matvec_cached(self, zcache, vec, out, workspace):
         ext.hipZCacheMatvecScaled(zcache, vec, out, 1.0, workspace)
 
+    def block_ok(self):
+        return self.num_rffs % 4 == 0
+
+    def ztz_block_cached(self, zcache, vecs, out, workspace, accumulate=False):
+        _block_matvec(zcache, vecs, out, workspace, False, 1.0, accumulate)
+
     def workspace_bytes(self):
         return ext.ztz_workspace_bytes(self.num_rffs, self.radem_diag.shape[2])
+
+    def kernel_specific_gradient(self, input_x, sequence_length):
+        """conv_kernel_baseclass.py:157-190."""
+        if sequence_length is None:
+            raise RuntimeError("sequence_length is required for convolution kernels.")
+        if input_x.shape[2] != self._xdim[2]:
+            raise RuntimeError("Unexpected input shape supplied.")
+        if isinstance(sequence_length, torch.Tensor):
+            sequence_length = sequence_length.cpu().numpy()
+        slen = np.ascontiguousarray(sequence_length.astype(np.int32, copy=False))
+        n = input_x.shape[0]
+        xtrans = torch.zeros((n, self.num_rffs), dtype=torch.float64, device=self.device)
+        dz_dsigma = torch.zeros((n, self.num_rffs, 1), dtype=torch.float64, device=self.device)
+        ext.hipConvGrad(input_x, xtrans, self.radem_diag, self.chi_arr, slen, dz_dsigma,
+                        float(self.hyperparams[1]), self.conv_width, self.scaling_type)
+        return xtrans, dz_dsigma
 
     def kernel_specific_transform(self, input_x, sequence_length):
         """conv_kernel_baseclass.py:116-147."""

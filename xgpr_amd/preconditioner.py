@@ -119,6 +119,21 @@ class RandNysPreconditioner:
         xprod2 = xvec - (self.u_mat @ xprod)
         return xprod2 + xprod1
 
+    def get_logdet(self):
+        """rand_nys_preconditioners.py:96-102."""
+        logdet = 1 + (self.eig - self.prefactor) / self.prefactor
+        return float(torch.log(logdet.clamp(min=1e-12)).sum().item())
+
+    def matvec_for_sampling(self, xvec):
+        """rand_nys_preconditioners.py:105-119: the square root of the preconditioner's inverse applied
+        to probe vectors, so that they are drawn from N(0, P)."""
+        eigvals = self.eig.clamp(min=0).sqrt()
+        prefactor = (1 / self.prefactor) ** 0.5
+        xprod = self.u_mat.T @ xvec
+        xprod1 = self.u_mat @ (eigvals[:, None] * prefactor * xprod)
+        xprod2 = xvec - (self.u_mat @ xprod)
+        return xprod1 + xprod2
+
     def get_rank(self):
         return self.inv_eig.shape[0]
 

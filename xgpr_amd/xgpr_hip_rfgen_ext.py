@@ -302,6 +302,24 @@ def hipZCacheMatvec(cacheArr, vec, outVec, fitIntercept, workspace):
         C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
 
 
+def hipZCacheBlockMatvec(cacheArr, vecs, outVecs, fitIntercept, workspace, scale=0.0, accumulate=False):
+    """``outVecs (+)= Z.T @ (Z @ vecs)`` for vecs [num_rffs, k <= 32] on the float64 matrix cores, Z streamed
+    from the resident feature cache (cg_tools.py:41-44 with a block of right-hand sides).  scale = 0 selects
+    the RBF-family scale; a positive scale is for caches that already hold complete feature rows / scale."""
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    v = _dev(vecs, "vecs", torch.float64, 2)
+    o = _dev(outVecs, "outVecs", torch.float64, 2)
+    if vecs.shape[0] != cacheArr.shape[1] or tuple(outVecs.shape) != tuple(vecs.shape):
+        raise TypeError("vecs / outVecs: expected [num_rffs, k]")
+    return _lib.check(_LIB.xgpr_zcache_block_matvec_f32(
+        zc, v, o, cacheArr.shape[0], cacheArr.shape[1], vecs.shape[1], int(bool(fitIntercept)), float(scale),
+        int(bool(accumulate)), C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
+
+
+def zcache_block_workspace_bytes(ndatapoints, num_rffs, k):
+    return int(_LIB.xgpr_zcache_block_workspace_bytes(ndatapoints, num_rffs, k))
+
+
 def ztz_workspace_bytes(num_rffs, radem_shape2):
     return int(_LIB.xgpr_ztz_matvec_workspace_bytes(num_rffs, radem_shape2))
 
