@@ -65,7 +65,7 @@ class ConjugateGrad:
             if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != xs.device:
                 self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=xs.device)
             self._matvec_cols(kernel, xs, vec, matvec)
-        elif vec.is_cuda and hasattr(kernel, "block_ok") and kernel.block_ok():
+        elif self.BLOCK_KERNELS and vec.is_cuda and hasattr(kernel, "block_ok") and kernel.block_ok():
             self._matvec_block(dataset, kernel, vec, matvec)
         else:
             for x, lengths in dataset.get_chunked_x_data():
@@ -74,7 +74,8 @@ class ConjugateGrad:
         self.comm.all_reduce_(matvec)
         matvec += kernel.get_lambda() ** 2 * vec
 
-    BLOCK_WINDOW_BYTES = 2 << 30        # scratch for regenerated float32 feature rows
+    BLOCK_KERNELS = True                # False: chunked float64 Z + library GEMMs (kept for timing comparisons)
+    BLOCK_WINDOW_BYTES = 8 << 30        # scratch for regenerated float32 feature rows (a window fills the GPU twice over)
 
     def _block_ws(self, nrows, kernel, k, dev):
         from .kernels import block_workspace_bytes

@@ -1177,7 +1177,6 @@ struct ZbArgs {
 constexpr int ZB_FEATS = 16;      // features per LDS chunk of V (T kernel)
 constexpr int ZB_ROWS = 32;       // datapoints per LDS chunk of T (W kernel)
 constexpr int ZB_RING = 4;        // chunks of the streamed operand per wave: ZB_RING - 1 in flight, one consumed
-constexpr int ZB_TROWS = 512;     // datapoints per workgroup of the T kernel (8 waves x 64)
 constexpr int ZB_WFEATS = 512;    // features per workgroup of the W kernel (8 waves x 64)
 
 // Both kernels: 8 waves per workgroup (the CU places a 4-wave workgroup's waves on two SIMDs, which
@@ -1189,7 +1188,7 @@ __device__ __forceinline__ double elem(const float4 &v, int e) {
     return (double)(e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w);
 }
 
-template <int CT>
+template <int CT, int ZB_RT>
 __global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
     constexpr int KP = 16 * CT;
     constexpr int VS = KP + 4;                     // +32 B per row: lane groups g and g+1 land 128 B apart
@@ -1198,30 +1197,30 @@ __global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
     __shared__ __attribute__((aligned(16))) double vs[2][ZB_FEATS * VS];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long rbase = (long)blockIdx.x * ZB_TROWS + 64 * w;
-    const float *rp[4];
+    const long rbase = (long)blockIdx.x * (128 * ZB_RT) + 16 * ZB_RT * w;
+    const float *rp[ZB_RT];
     #pragma unroll
-    for (int rt = 0; rt < 4; rt++) {
+    for (int rt = 0; rt < ZB_RT; rt++) {
         long row = rbase + 16 * rt + c;
         if (row >= a.n) row = a.n - 1;             // clamped rows are computed and never stored
         rp[rt] = a.zc + row * a.M + 4 * g;
     }
-    double4_t acc[4][CT];
+    double4_t acc[ZB_RT][CT];
     #pragma unroll
-    for (int rt = 0; rt < 4; rt++)
+    for (int rt = 0; rt < ZB_RT; rt++)
         #pragma unroll
         for (int ct = 0; ct < CT; ct++) acc[rt][ct] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const long nchunks = (a.M + ZB_FEATS - 1) / ZB_FEATS;
     const double inv_scale = 1.0 / a.scale;
     const long fmax = a.M - 4 - 4 * g;             // last float4 of a row, relative to rp
 
-    auto load_a = [&](long ch, float4 (&dst)[QG][4]) {
+    auto load_a = [&](long ch, float4 (&dst)[QG][ZB_RT]) {
         #pragma unroll
         for (int q = 0; q < QG; q++) {
             long f = ch * ZB_FEATS + 16 * q;
             if (f > fmax) f = fmax;                // past the last feature: V supplies the zeros
             #pragma unroll
-            for (int rt = 0; rt < 4; rt++) dst[q][rt] = *reinterpret_cast<const float4 *>(rp[rt] + f);
+            for (int rt = 0; rt < ZB_RT; rt++) dst[q][rt] = *reinterpret_cast<const float4 *>(rp[rt] + f);
         }
     };
     auto load_v = [&](long ch, double (&dst)[VPT]) {
@@ -1242,7 +1241,7 @@ __global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
             if (idx < ZB_FEATS * KP) vs[buf][(idx / KP) * VS + idx % KP] = src[e];
         }
     };
-    auto compute = [&](long ch, const float4 (&cur)[QG][4]) {
+    auto compute = [&](long ch, const float4 (&cur)[QG][ZB_RT]) {
         const bool first = a.fit_intercept && ch == 0 && g == 0;
         const double *vb = vs[ch & 1];
         #pragma unroll
@@ -1253,7 +1252,7 @@ __global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
                 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) b[ct] = vb[(16 * q + 4 * g + e) * VS + 16 * ct + c];
                 #pragma unroll
-                for (int rt = 0; rt < 4; rt++) {
+                for (int rt = 0; rt < ZB_RT; rt++) {
                     double av = elem(cur[q][rt], e);
                     if (q == 0 && e == 0 && first) av = inv_scale;     // Z[:, 0] = 1 (kernel_baseclass.py:296-297)
                     #pragma unroll
@@ -1266,7 +1265,7 @@ __global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
     };
 
     static_assert(ZB_RING == 4, "the stage loop below is unrolled for a ring of 4");
-    float4 ring[ZB_RING][QG][4];
+    float4 ring[ZB_RING][QG][ZB_RT];
     double vreg[ZB_RING][VPT];
     #pragma unroll
     for (int i = 0; i < ZB_RING - 1; i++) { load_v(i, vreg[i]); load_a(i, ring[i]); }
@@ -1287,7 +1286,7 @@ __global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
     }
 #undef ZB_STAGE
     #pragma unroll
-    for (int rt = 0; rt < 4; rt++)
+    for (int rt = 0; rt < ZB_RT; rt++)
         #pragma unroll
         for (int r = 0; r < 4; r++) {
             const long row = rbase + 16 * rt + g + 4 * r;
@@ -2059,17 +2058,24 @@ int zcache_block_impl(const float *zc, const double *V, double *W, long n, long 
     a.n = n; a.M = num_rffs; a.k = (int)k; a.fit_intercept = fit_intercept;
     a.scale = scale_override > 0.0 ? scale_override : rbf_scale<float>(num_rffs / 2, fit_intercept);
     a.rows_per_range = gm.rows_per_range;
-    const long tblocks = (n + ZB_TROWS - 1) / ZB_TROWS;
+    // T kernel: 16 RT datapoints per wave, 8 waves; RT = 4 reuses each LDS operand most, smaller RT
+    // keeps every CU busy when the shard (or window) is short
+    const long cus = device_cus();
+    const int rt = n >= 2 * cus * 512 ? 4 : n >= 2 * cus * 256 ? 2 : 1;
+    const long tblocks = (n + 128 * rt - 1) / (128 * rt);
     if (tblocks > 2147483647L || gm.nrb > 65535) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
+    const dim3 tg((unsigned)tblocks), wg((unsigned)gm.mblk, (unsigned)gm.nrb), blk(512);
+#define ZB_LAUNCH_T(CT, RT) hipLaunchKernelGGL((zblock_t_kernel<CT, RT>), tg, blk, 0, st, a)
     if (gm.kp == 16) {
-        hipLaunchKernelGGL(zblock_t_kernel<1>, dim3((unsigned)tblocks), dim3(512), 0, st, a);
+        if (rt == 4) ZB_LAUNCH_T(1, 4); else if (rt == 2) ZB_LAUNCH_T(1, 2); else ZB_LAUNCH_T(1, 1);
         HIP_TRY(hipGetLastError(), "zblock_t_kernel launch");
-        hipLaunchKernelGGL(zblock_w_kernel<1>, dim3((unsigned)gm.mblk, (unsigned)gm.nrb), dim3(512), 0, st, a);
+        hipLaunchKernelGGL(zblock_w_kernel<1>, wg, blk, 0, st, a);
     } else {
-        hipLaunchKernelGGL(zblock_t_kernel<2>, dim3((unsigned)tblocks), dim3(512), 0, st, a);
+        if (rt == 4) ZB_LAUNCH_T(2, 4); else if (rt == 2) ZB_LAUNCH_T(2, 2); else ZB_LAUNCH_T(2, 1);
         HIP_TRY(hipGetLastError(), "zblock_t_kernel launch");
-        hipLaunchKernelGGL(zblock_w_kernel<2>, dim3((unsigned)gm.mblk, (unsigned)gm.nrb), dim3(512), 0, st, a);
+        hipLaunchKernelGGL(zblock_w_kernel<2>, wg, blk, 0, st, a);
     }
+#undef ZB_LAUNCH_T
     HIP_TRY(hipGetLastError(), "zblock_w_kernel launch");
     const long total = num_rffs * gm.kp;
     hipLaunchKernelGGL(reduce_block_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.wpart, W,
