@@ -218,6 +218,20 @@ int xgpr_zcache_block_matvec_f32(const float *zc, const double *v, double *w_out
                                  long k, int fit_intercept, double scale, int accumulate,
                                  void *workspace, size_t workspace_bytes, void *stream);
 
+/* The two contractions of the block matvec on their own -- what the classifier's cost function
+ * does per chunk (fitting_toolkit/nonlinear_cg_toolkit.py:251-269: `pred = xd @ wvec`, then
+ * `grad[:,k] += ((pred[:,k] - targets)[:,None] * xd).sum(axis=0)`), and `xfeatures @ weights` in
+ * predict (xgp_classification.py:96-102):
+ *   project:      t_out[n, k]        =  Z v        v     [num_rffs, k]
+ *   backproject:  g_out[num_rffs, k] (+)= Z^T r    r     [n, k]
+ * with Z = scale * zc and Z[:,0] = 1 under fit_intercept; all float64, C-contiguous.  The projection
+ * needs no workspace; the back-projection takes xgpr_zcache_block_workspace_bytes(n, num_rffs, k). */
+int xgpr_zcache_block_project_f32(const float *zc, const double *v, double *t_out, long n, long num_rffs,
+                                  long k, int fit_intercept, double scale, void *stream);
+int xgpr_zcache_block_backproject_f32(const float *zc, const double *r, double *g_out, long n, long num_rffs,
+                                      long k, int fit_intercept, double scale, int accumulate,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- self test of the cross-lane butterfly stages the wave-level FHT is built on: for each
  * of the 6 lane strides h = 1, 2, 4, 8, 16, 32 runs one stage on v[r] = lane + 64 r
  * (r = 0..15) and writes the result to out[6][16][64] (int32, device).  Expected:

@@ -733,3 +733,121 @@ def exact_nmll_gradient(kernel, dataset):
         grad[i + 1] = float(g)
     grad *= hparams
     return float(negloglik), grad
+
+
+# ---------------------------------------------------------------------------------------
+# Classification (fitting_toolkit/nonlinear_cg_toolkit.py, xgp_classification.py)
+# ---------------------------------------------------------------------------------------
+class OracleClassificationDataset(OracleDataset):
+    """data_handling/dataset_builder.py:68-117, :182-188: integer labels, no y normalisation."""
+
+    def __init__(self, x, y, seqlen=None, chunk_size=2000):
+        if not np.issubdtype(y.dtype, np.integer):
+            raise RuntimeError("For classification, ydata must be an array of integers.")
+        if y.min() != 0:
+            raise RuntimeError("For classification, there must be a zero category.")
+        super().__init__(x, y, seqlen, chunk_size, normalize_y=False)
+        self.y = y
+        self.n_classes = int(y.max()) + 1
+
+    def get_n_classes(self):
+        return self.n_classes
+
+    def get_chunked_data(self):
+        n = self.x.shape[0]
+        for i in range(0, n, self.chunk_size):
+            j = min(i + self.chunk_size, n)
+            yield self.x[i:j], self.y[i:j], None if self.seqlen is None else self.seqlen[i:j]
+
+
+def _softmax_ref(pred):
+    """the reference's softmax: base 2.71828, not e (nonlinear_cg_toolkit.py:252-254)."""
+    pred = pred - pred.max(axis=1)[:, None]
+    pred = 2.71828 ** pred
+    return pred / pred.sum(axis=1)[:, None]
+
+
+def classification_cost(dataset, kernel, wvec):
+    """nonlinear_cg_toolkit.py:231-275 -> (grad, loss)."""
+    lam = kernel.get_lambda()
+    grad = np.zeros(wvec.shape)
+    grad[1:, :] += lam ** 2 * wvec[1:, :]
+    loss = 0.5 * lam ** 2 * (wvec ** 2)[1:, :].sum()
+    for xd, yd, ld in dataset.get_chunked_data():
+        z = kernel.transform_x(xd, ld)
+        yd = yd.astype(np.int32)
+        pred = _softmax_ref(z @ wvec)
+        loss -= float(np.log(pred.clip(min=1e-16))[np.arange(pred.shape[0]), yd].sum())
+        for k in range(wvec.shape[1]):
+            grad[:, k] += ((pred[:, k] - (yd == k).astype(np.float64))[:, None] * z).sum(axis=0)
+    return grad, float(loss)
+
+
+def fit_classifier(dataset, kernel, preconditioner=None, max_iter=500, tol=1e-4):
+    """nonlinear_cg_toolkit.py:72-226 -> (weights, n_iter, losses)."""
+    state = {"last_grad": None, "last_sd": None, "n_iter": 0}
+
+    def cost(w):
+        return classification_cost(dataset, kernel, w)
+
+    def update(grad, wvec, loss, previous_loss):
+        sd = preconditioner.batch_matvec(grad) if preconditioner is not None else grad
+        if state["last_grad"] is not None:
+            pr = (sd * (grad - state["last_grad"])).sum() / (state["last_grad"] * state["last_sd"]).sum()
+            pr = max(0., float(pr))
+            correction = pr * state["last_sd"]
+            state["last_grad"], state["last_sd"] = grad.copy(), sd.copy()
+            sd += correction           # in place: aliases grad when there is no preconditioner (:136, :148)
+        else:
+            state["last_grad"], state["last_sd"] = grad.copy(), sd.copy()
+        sd = -sd
+        a0p = (grad * sd).sum()
+        a_init = 1 if previous_loss is None else 2 * (loss - previous_loss) / a0p
+        w_full = wvec + a_init * sd
+        g_full, l_full = cost(w_full)
+        if state["n_iter"] >= 10 and np.abs(np.abs(l_full - loss) / loss) > tol \
+                and l_full < (loss + a_init * 1e-4 * a0p):
+            return g_full, l_full, w_full
+        a_quad = -(a0p * a_init ** 2) / (2 * (l_full - loss - a0p * a_init))
+        w_quad = wvec + a_quad * sd
+        g_quad, l_quad = cost(w_quad)
+        if l_quad < l_full:
+            if l_quad < (loss + a_quad * 1e-4 * a0p):
+                return g_quad, l_quad, w_quad
+        elif l_full < (loss + a_init * 1e-4 * a0p):
+            return g_full, l_full, w_full
+        cand = [(loss, grad, wvec), (l_full, g_full, w_full), (l_quad, g_quad, w_quad)]
+        a_max = a_quad if l_quad < l_full else a_init
+        rfactor = 0.5
+        for _ in range(10):
+            a = rfactor * a_max
+            w_c = wvec + a * sd
+            g_c, l_c = cost(w_c)
+            if l_c < (loss + a * 1e-4 * a0p):
+                return g_c, l_c, w_c
+            cand.append((l_c, g_c, w_c))
+            rfactor *= 0.5
+        best = int(np.argmin([c[0] for c in cand]))
+        return cand[best][1], cand[best][0], cand[best][2]
+
+    wvec = np.zeros((kernel.get_num_rffs(), dataset.get_n_classes()))
+    grad, loss = cost(wvec)
+    losses = [loss]
+    last_alpha = None
+    while state["n_iter"] < max_iter:
+        grad, loss, wvec = update(grad, wvec, loss, last_alpha)
+        losses.append(loss)
+        if np.abs(np.abs(losses[-1] - losses[-2]) / losses[-2]) < tol:
+            break
+        state["n_iter"] += 1
+        last_alpha = losses[state["n_iter"] - 1]
+    return wvec, state["n_iter"], losses
+
+
+def predict_proba(kernel, weights, input_x, sequence_lengths=None, gamma=None):
+    """xgp_classification.py:59-109."""
+    z = kernel.transform_x(input_x, sequence_lengths)
+    pred = z @ weights
+    if gamma is not None:
+        pred = pred + gamma[None, :]
+    return _softmax_ref(pred)

@@ -427,6 +427,45 @@ def g10_nmll(xgpr):
     save("g10_nmll.npz", **out)
 
 
+def g11_classifier(xgpr):
+    """xGPClassification on the wine data of the reference's own classifier test
+    (tests/utils/build_classification_dataset.py:15-44, tests/fitting_tests/test_cg_fit.py:76-91:
+    RBF, DISCRIM_HPARAM = (-1, -0.75), rank-256 "srht" preconditioner, tol 1e-2 => niter < 10; 1024
+    RFFs here to keep the file small): the first cost-function evaluation, the nonlinear-CG losses,
+    the weights and the class probabilities (fitting_toolkit/nonlinear_cg_toolkit.py:72-275,
+    xgp_classification.py:59-109).  The standardised inputs are stored with the outputs."""
+    import sklearn.datasets
+    from sklearn.preprocessing import StandardScaler
+    from xGPR import xGPClassification
+    from xGPR.data_handling.dataset_builder import build_classification_dataset
+    from xGPR.fitting_toolkit.nonlinear_cg_toolkit import nonlinear_CG_classification
+    xvalues, yvalues = sklearn.datasets.load_wine(return_X_y=True)
+    xvalues = StandardScaler().fit_transform(xvalues)
+    rng = np.random.default_rng(123)
+    idx = rng.permutation(xvalues.shape[0])
+    xvalues, yvalues = xvalues[idx, :], yvalues[idx]
+    cutoff = int(0.75 * idx.shape[0])
+    xtr, ytr, xte, yte = xvalues[:cutoff], yvalues[:cutoff], xvalues[cutoff:], yvalues[cutoff:]
+    ds = build_classification_dataset(xtr, ytr, chunk_size=2000)
+    hparam = np.array([-1, -0.75])
+    mod = xGPClassification(num_rffs=1024, kernel_choice="RBF", random_seed=123, device="cpu",
+                            kernel_settings={"intercept": True}, verbose=False)
+    mod.set_hyperparams(hparam, ds)
+    pre, ratio = mod.build_preconditioner(ds, max_rank=256, method="srht")
+    # one cost-function evaluation at a fixed, non-trivial weight matrix
+    wrng = np.random.default_rng(7)
+    w_probe = 0.05 * wrng.standard_normal((1024, int(ds.get_n_classes())))
+    op = nonlinear_CG_classification(ds, mod.kernel, "cpu", False, pre)
+    grad_probe, loss_probe = op.cost_fun_classification(w_probe)
+    niter, losses = mod.fit(ds, preconditioner=pre, max_iter=500, run_diagnostics=True, tol=1e-2)
+    probs = mod.predict(xte)
+    print(f"  G11: niter={niter} losses={losses[:3]}... test acc={(probs.argmax(axis=1) == yte).mean():.3f}")
+    save("g11_classifier.npz", xtrain=xtr, ytrain=ytr.astype(np.int64), xtest=xte, ytest=yte.astype(np.int64),
+         hparam_log=hparam.astype(np.float64), ratio=np.float64(ratio), w_probe=w_probe, grad_probe=grad_probe,
+         loss_probe=np.float64(loss_probe), niter=np.int64(niter), losses=np.asarray(losses),
+         weights=np.asarray(mod.weights), probs=probs)
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -439,3 +478,4 @@ if __name__ == "__main__":
     g8_e2e(xgpr)
     g9_exact(xgpr)
     g10_nmll(xgpr)
+    g11_classifier(xgpr)

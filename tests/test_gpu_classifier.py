@@ -1,0 +1,103 @@
+"""GPU parity of the classifier row: the two halves of the block matvec
+(projection / back-projection on the float64 matrix cores), the classification cost function, the
+preconditioned nonlinear CG fit and the predicted probabilities, against values the REFERENCE's own
+Python produced on its own classifier test data (tests/golden/g11_classifier.npz) and against the
+oracle.  Tolerance 1e-5 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("n,m,k,icpt", [(133, 1024, 3, True), (1, 8, 1, False), (700, 260, 17, True),
+                                        (4097, 512, 32, False)])
+def test_project_and_backproject_vs_float64_product(n, m, k, icpt):
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    g = torch.Generator(device=DEV).manual_seed(n + m)
+    zc = torch.rand((n, m), dtype=torch.float32, device=DEV, generator=g) * 2 - 1
+    v = torch.randn((m, k), dtype=torch.float64, device=DEV, generator=g)
+    r = torch.randn((n, k), dtype=torch.float64, device=DEV, generator=g)
+    scale = float(np.float32(np.sqrt(1.0 / (m // 2 - 0.5 if icpt else m // 2))))
+    z = zc.double() * scale
+    if icpt:
+        z[:, 0] = 1.0
+    t = torch.full((n, k), 3.0, dtype=torch.float64, device=DEV)
+    ext.hipZCacheBlockProject(zc, v, t, icpt)
+    assert rel(t, (z @ v).cpu().numpy()) < 1e-13
+    gout = torch.full((m, k), 5.0, dtype=torch.float64, device=DEV)
+    ws = torch.empty(ext.zcache_block_workspace_bytes(n, m, k), dtype=torch.uint8, device=DEV)
+    ext.hipZCacheBlockBackproject(zc, r, gout, icpt, ws)
+    ref = (z.T @ r).cpu().numpy()
+    assert rel(gout, ref) < 1e-13
+    ext.hipZCacheBlockBackproject(zc, r, gout, icpt, ws, accumulate=True)
+    assert rel(gout, 2 * ref) < 1e-13
+    # explicit scale (complete feature rows, as the convolution kernels cache them)
+    ext.hipZCacheBlockProject(zc, v, t, False, 0.5)
+    assert rel(t, (0.5 * zc.double() @ v).cpu().numpy()) < 1e-13
+
+
+@pytest.mark.parametrize("cache", [False, True])
+def test_g11_classifier_vs_reference(cache):
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_classification_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.classification import NonlinearCGClassification, fit_classifier, predict_proba
+    g = load_golden("g11_classifier.npz")
+    x, y = g["xtrain"], g["ytrain"]
+    ds = build_classification_dataset(x, y, chunk_size=2000, device=DEV)
+    assert ds.get_n_classes() == 3 and ds.get_ndatapoints() == x.shape[0]
+    kern = make_kernel("RBF", x.shape, 1024, 123, DEV, {"intercept": True})
+    kern.set_hyperparams(g["hparam_log"], logspace=True)
+    pre = RandNysPreconditioner(kern, ds, 256, False, 123, "srht", is_regression=False)
+    assert pre.get_zty() is None
+    op = NonlinearCGClassification(ds, kern, False, pre, cache_features=cache)
+    grad, loss = op.cost_fun_classification(torch.from_numpy(g["w_probe"]).to(DEV))
+    assert np.isclose(loss, float(g["loss_probe"]), rtol=1e-6)
+    assert rel(grad, g["grad_probe"]) < 1e-5
+    w, gamma, niter, losses = fit_classifier(kern, ds, pre, tol=1e-2, max_iter=500, cache_features=cache)
+    assert niter == int(g["niter"]) and niter < 10        # the reference's acceptance bar
+    assert np.allclose(losses, g["losses"], rtol=1e-5)
+    assert rel(w, g["weights"]) < 1e-4                     # line-search steps amplify rounding ~10x
+    probs = predict_proba(kern, w, gamma, torch.from_numpy(g["xtest"]).to(DEV))
+    assert np.allclose(probs.cpu().numpy(), g["probs"], rtol=1e-4, atol=1e-6)
+    assert (probs.argmax(dim=1).cpu().numpy() == g["ytest"]).mean() > 0.9
+
+
+def test_classifier_conv_kernel_matches_oracle(oracle):
+    """Sequence kernel + no preconditioner (the reference's aliasing of the search direction with the
+    gradient included): cost function and a short fit against the oracle."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_classification_dataset
+    from xgpr_amd.classification import NonlinearCGClassification
+    rng = np.random.default_rng(31)
+    n, L, C, m, ncls = 240, 16, 5, 64, 4
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(4, L + 1, size=n).astype(np.int32)
+    y = rng.integers(0, ncls, size=n).astype(np.int64)
+    y[:ncls] = np.arange(ncls)
+    hp = np.array([0.8, 0.6])
+    ds = build_classification_dataset(x, y, sl, chunk_size=100, device=DEV)
+    kern = make_kernel("Conv1dRBF", x.shape, m, 123, DEV, {"conv_width": 3, "averaging": "sqrt"})
+    kern.set_hyperparams(hp, logspace=False)
+    ods = orc.OracleClassificationDataset(x.astype(np.float64), y, sl, chunk_size=100)
+    okern = orc.OracleKernel("Conv1dRBF", m, x.shape, hp, 123, conv_width=3, averaging="sqrt", ops=oracle)
+    w0 = 0.1 * rng.standard_normal((m, ncls))
+    op = NonlinearCGClassification(ds, kern, False, None, cache_features=False)
+    grad, loss = op.cost_fun_classification(torch.from_numpy(w0).to(DEV))
+    gref, lref = orc.classification_cost(ods, okern, w0)
+    assert np.isclose(loss, lref, rtol=1e-6) and rel(grad, gref) < 1e-5
+    w, niter, losses = op.fit_model(max_iter=6, tol=1e-6)
+    wref, nref, lossref = orc.fit_classifier(ods, okern, None, 6, 1e-6)
+    assert niter == nref
+    assert np.allclose(losses, lossref, rtol=1e-5)
+    assert rel(w, wref) < 1e-4

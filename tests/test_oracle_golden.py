@@ -246,3 +246,25 @@ def test_g10_nmll_oracle_vs_reference(oracle, tag):
     assert np.isclose(approx, float(g[f"{tag}_approx_nmll"]), rtol=1e-7)
     # the reference's own acceptance test: approximate within 1 % of exact (test_slq_nmll.py:73-79)
     assert 100 * abs(approx - float(g[f"{tag}_exact_nmll"])) / float(g[f"{tag}_exact_nmll"]) < 1.0
+
+
+def test_g11_classifier_oracle_vs_reference(oracle):
+    """xGPClassification on the wine data of the reference's own classifier test (reference
+    tests/fitting_tests/test_cg_fit.py:76-91): one cost-function evaluation, the nonlinear-CG loss
+    sequence, the fitted weights and the predicted class probabilities."""
+    g = load_golden("g11_classifier.npz")
+    x, y = g["xtrain"], g["ytrain"]
+    ds = orc.OracleClassificationDataset(x, y, chunk_size=2000)
+    assert ds.get_n_classes() == 3
+    kern = orc.OracleKernel("RBF", 1024, x.shape, np.exp(g["hparam_log"]), 123, ops=oracle)
+    grad, loss = orc.classification_cost(ds, kern, g["w_probe"])
+    assert np.isclose(loss, float(g["loss_probe"]), rtol=1e-10)
+    assert np.allclose(grad, g["grad_probe"], rtol=1e-8, atol=1e-10)
+    pre = orc.OracleRandNysPreconditioner(kern, ds, 256, 123, "srht")
+    w, niter, losses = orc.fit_classifier(ds, kern, pre, 500, 1e-2)
+    assert niter == int(g["niter"]) and niter < 10
+    assert np.allclose(losses, g["losses"], rtol=1e-6)
+    assert np.linalg.norm(w - g["weights"]) <= 1e-5 * np.linalg.norm(g["weights"])
+    probs = orc.predict_proba(kern, w, g["xtest"])
+    assert np.allclose(probs, g["probs"], rtol=1e-5, atol=1e-7)
+    assert (probs.argmax(axis=1) == g["ytest"]).mean() > 0.9

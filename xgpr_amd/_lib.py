@@ -40,6 +40,8 @@ SIGNATURES = {
     "xgpr_zcache_matvec_f32": [_vp, _vp, _vp, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_zcache_matvec_scaled_f32": [_vp, _vp, _vp, _l, _l, _d, _vp, _sz, _vp],
     "xgpr_zcache_block_matvec_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _i, _vp, _sz, _vp],
+    "xgpr_zcache_block_project_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _vp],
+    "xgpr_zcache_block_backproject_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _i, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
 }
 SIZE_FUNCS = {

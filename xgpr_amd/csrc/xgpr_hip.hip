@@ -1172,6 +1172,8 @@ struct ZbArgs {
     const float *zc; const double *V; double *T; double *wpart;
     long n; long M; int k; int fit_intercept; double scale;
     long rows_per_range;
+    long ldt;            // row pitch of T in doubles: 16 CT inside the fused matvec, k for a caller's [n, k] array
+    double tscale;       // factor applied to T at the store (1 inside the fused matvec, scale for the projection)
 };
 
 constexpr int ZB_FEATS = 16;      // features per LDS chunk of V (T kernel)
@@ -1292,7 +1294,8 @@ __global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
             const long row = rbase + 16 * rt + g + 4 * r;
             if (row < a.n) {
                 #pragma unroll
-                for (int ct = 0; ct < CT; ct++) a.T[row * KP + 16 * ct + c] = acc[rt][ct][r];
+                for (int ct = 0; ct < CT; ct++)
+                    if (16 * ct + c < a.ldt) a.T[row * a.ldt + 16 * ct + c] = acc[rt][ct][r] * a.tscale;
             }
         }
 }
@@ -1335,8 +1338,8 @@ __global__ __launch_bounds__(512, 1) void zblock_w_kernel(ZbArgs a) {
         for (int e = 0; e < TPT; e++) {
             const int idx = threadIdx.x + 512 * e;
             const long row = rbeg + ch * ZB_ROWS + idx / KP;
-            const bool ok = idx < ZB_ROWS * KP && row < rend;
-            const double v = a.T[(ok ? row : rend - 1) * KP + idx % KP];
+            const bool ok = idx < ZB_ROWS * KP && row < rend && idx % KP < a.ldt;
+            const double v = a.T[ok ? row * a.ldt + idx % KP : 0];
             dst[e] = ok ? v : 0.0;
         }
     };
@@ -2041,23 +2044,37 @@ ZbGeom zb_geometry(long n, long num_rffs, long k) {
     return gm;
 }
 
-int zcache_block_impl(const float *zc, const double *V, double *W, long n, long num_rffs, long k, int fit_intercept,
-                      double scale_override, int accumulate, void *workspace, size_t wbytes, void *stream) {
+enum { ZB_MATVEC = 0, ZB_PROJECT = 1, ZB_BACKPROJECT = 2 };
+
+// mode ZB_MATVEC:      out[M, k] (+)= s^2 Zc^T (Zc in),  in = V [M, k]
+// mode ZB_PROJECT:     out[n, k]  =  s Zc in,            in = V [M, k]      (T kernel only)
+// mode ZB_BACKPROJECT: out[M, k] (+)= s Zc^T in,         in = R [n, k]      (W kernel + reduce)
+int zcache_block_impl(int mode, const float *zc, const double *in, double *out, long n, long num_rffs, long k,
+                      int fit_intercept, double scale_override, int accumulate, void *workspace, size_t wbytes,
+                      void *stream) {
     if (n <= 0) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
     if (num_rffs < 4 || (num_rffs & 3) != 0) return fail(XGPR_ERR_UNSUPPORTED, "block matvec needs num_rffs to be a multiple of 4");
     if (k < 1 || k > 32) return fail(XGPR_ERR_UNSUPPORTED, "block matvec takes 1..32 right-hand sides per call");
     if (!aligned16(zc)) return fail(XGPR_ERR_WORKSPACE, "cache pointer must be 16-byte aligned");
     const ZbGeom gm = zb_geometry(n, num_rffs, k);
-    if (!workspace || wbytes < gm.t_bytes + gm.slab_bytes || !aligned16(workspace))
+    if (mode != ZB_PROJECT && (!workspace || wbytes < gm.t_bytes + gm.slab_bytes || !aligned16(workspace)))
         return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_zcache_block_workspace_bytes)");
     hipStream_t st = (hipStream_t)stream;
     ZbArgs a = {};
-    a.zc = zc; a.V = V;
-    a.T = reinterpret_cast<double *>(workspace);
-    a.wpart = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(workspace) + gm.t_bytes);
+    a.zc = zc; a.V = in;
     a.n = n; a.M = num_rffs; a.k = (int)k; a.fit_intercept = fit_intercept;
     a.scale = scale_override > 0.0 ? scale_override : rbf_scale<float>(num_rffs / 2, fit_intercept);
     a.rows_per_range = gm.rows_per_range;
+    a.ldt = gm.kp; a.tscale = 1.0;
+    if (mode == ZB_MATVEC) {
+        a.T = reinterpret_cast<double *>(workspace);
+    } else if (mode == ZB_PROJECT) {
+        a.T = out; a.ldt = k; a.tscale = a.scale;
+    } else {
+        a.T = const_cast<double *>(in); a.ldt = k;
+    }
+    if (mode != ZB_PROJECT)
+        a.wpart = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(workspace) + gm.t_bytes);
     // T kernel: 16 RT datapoints per wave, 8 waves; RT = 4 reuses each LDS operand most, smaller RT
     // keeps every CU busy when the shard (or window) is short
     const long cus = device_cus();
@@ -2066,20 +2083,22 @@ int zcache_block_impl(const float *zc, const double *V, double *W, long n, long 
     if (tblocks > 2147483647L || gm.nrb > 65535) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
     const dim3 tg((unsigned)tblocks), wg((unsigned)gm.mblk, (unsigned)gm.nrb), blk(512);
 #define ZB_LAUNCH_T(CT, RT) hipLaunchKernelGGL((zblock_t_kernel<CT, RT>), tg, blk, 0, st, a)
-    if (gm.kp == 16) {
-        if (rt == 4) ZB_LAUNCH_T(1, 4); else if (rt == 2) ZB_LAUNCH_T(1, 2); else ZB_LAUNCH_T(1, 1);
+    if (mode != ZB_BACKPROJECT) {
+        if (gm.kp == 16) {
+            if (rt == 4) ZB_LAUNCH_T(1, 4); else if (rt == 2) ZB_LAUNCH_T(1, 2); else ZB_LAUNCH_T(1, 1);
+        } else {
+            if (rt == 4) ZB_LAUNCH_T(2, 4); else if (rt == 2) ZB_LAUNCH_T(2, 2); else ZB_LAUNCH_T(2, 1);
+        }
         HIP_TRY(hipGetLastError(), "zblock_t_kernel launch");
-        hipLaunchKernelGGL(zblock_w_kernel<1>, wg, blk, 0, st, a);
-    } else {
-        if (rt == 4) ZB_LAUNCH_T(2, 4); else if (rt == 2) ZB_LAUNCH_T(2, 2); else ZB_LAUNCH_T(2, 1);
-        HIP_TRY(hipGetLastError(), "zblock_t_kernel launch");
-        hipLaunchKernelGGL(zblock_w_kernel<2>, wg, blk, 0, st, a);
     }
 #undef ZB_LAUNCH_T
+    if (mode == ZB_PROJECT) return 0;
+    if (gm.kp == 16) hipLaunchKernelGGL(zblock_w_kernel<1>, wg, blk, 0, st, a);
+    else hipLaunchKernelGGL(zblock_w_kernel<2>, wg, blk, 0, st, a);
     HIP_TRY(hipGetLastError(), "zblock_w_kernel launch");
     const long total = num_rffs * gm.kp;
-    hipLaunchKernelGGL(reduce_block_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.wpart, W,
-                       num_rffs, gm.kp, (int)k, gm.nrb, a.scale * a.scale, accumulate);
+    hipLaunchKernelGGL(reduce_block_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.wpart, out,
+                       num_rffs, gm.kp, (int)k, gm.nrb, mode == ZB_MATVEC ? a.scale * a.scale : a.scale, accumulate);
     HIP_TRY(hipGetLastError(), "reduce_block_slabs_kernel launch");
     return 0;
 }
@@ -2264,7 +2283,18 @@ size_t xgpr_zcache_block_workspace_bytes(long n, long num_rffs, long k) {
 int xgpr_zcache_block_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs, long k,
                                  int fit_intercept, double scale, int accumulate, void *workspace,
                                  size_t workspace_bytes, void *stream) {
-    return zcache_block_impl(zc, v, w_out, n, num_rffs, k, fit_intercept, scale, accumulate, workspace, workspace_bytes, stream);
+    return zcache_block_impl(ZB_MATVEC, zc, v, w_out, n, num_rffs, k, fit_intercept, scale, accumulate, workspace,
+                             workspace_bytes, stream);
+}
+int xgpr_zcache_block_project_f32(const float *zc, const double *v, double *t_out, long n, long num_rffs, long k,
+                                  int fit_intercept, double scale, void *stream) {
+    return zcache_block_impl(ZB_PROJECT, zc, v, t_out, n, num_rffs, k, fit_intercept, scale, 0, nullptr, 0, stream);
+}
+int xgpr_zcache_block_backproject_f32(const float *zc, const double *r, double *g_out, long n, long num_rffs, long k,
+                                      int fit_intercept, double scale, int accumulate, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    return zcache_block_impl(ZB_BACKPROJECT, zc, r, g_out, n, num_rffs, k, fit_intercept, scale, accumulate, workspace,
+                             workspace_bytes, stream);
 }
 
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {

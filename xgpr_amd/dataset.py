@@ -16,7 +16,7 @@ from .dist import SINGLE
 
 class DeviceDataset:
     def __init__(self, xdata, ydata, sequence_lengths=None, chunk_size=2000,
-                 trainy_mean=0.0, trainy_std=1.0, ndatapoints=None, device="cuda", comm=SINGLE):
+                 trainy_mean=0.0, trainy_std=1.0, ndatapoints=None, device="cuda", comm=SINGLE, max_class=None):
         self.device = device
         self.comm = comm
         self._xdata = xdata
@@ -25,7 +25,12 @@ class DeviceDataset:
         self._chunk_size = int(chunk_size)
         self._trainy_mean, self._trainy_std = float(trainy_mean), float(trainy_std)
         self._ndatapoints = int(ndatapoints if ndatapoints is not None else xdata.shape[0])
+        self._max_class = max_class  # None for regression; the largest class label for classification
         self._scaled = {}
+
+    def get_n_classes(self):
+        """data_handling_baseclass.py:62-67."""
+        return None if self._max_class is None else self._max_class + 1
 
     # ---- the reference's accessors (data_handling_baseclass.py)
     def get_ndatapoints(self):
@@ -58,9 +63,12 @@ class DeviceDataset:
         n = self._xdata.shape[0]
         for i in range(0, n, self._chunk_size):
             j = min(i + self._chunk_size, n)
-            ychunk = self._ydata[i:j].to(torch.float64).clone()
-            ychunk -= self._trainy_mean
-            ychunk /= self._trainy_std
+            if self._max_class is None:
+                ychunk = self._ydata[i:j].to(torch.float64).clone()
+                ychunk -= self._trainy_mean
+                ychunk /= self._trainy_std
+            else:                                  # class labels go through unchanged
+                ychunk = self._ydata[i:j]
             lchunk = None if self._sequence_lengths is None else self._sequence_lengths[i:j]
             yield self._xdata[i:j, ...], ychunk, lchunk
 
@@ -126,3 +134,41 @@ def build_regression_dataset(xdata, ydata, sequence_lengths=None, chunk_size=200
     comm.all_reduce_(ssq)
     std = torch.sqrt(ssq[0] / stats[1])
     return DeviceDataset(xt, yt, sl, chunk_size, mean.item(), std.item(), n_global, device, comm)
+
+
+def build_classification_dataset(xdata, ydata, sequence_lengths=None, chunk_size=2000, device="cuda",
+                                 comm=SINGLE, already_sharded=False):
+    """dataset_builder.py:68-117, :150-190 for in-memory arrays: integer labels in [0, max_class] with a
+    zero category, no y normalisation.  Sharding as in ``build_regression_dataset``; the class count is
+    global."""
+    xt = torch.from_numpy(np.ascontiguousarray(xdata)) if isinstance(xdata, np.ndarray) else xdata
+    yt = torch.from_numpy(np.ascontiguousarray(ydata)) if isinstance(ydata, np.ndarray) else ydata
+    if yt.dim() != 1:
+        raise RuntimeError("Y must be a 1d numpy array.")
+    if yt.is_floating_point() or yt.dtype == torch.bool:
+        raise RuntimeError("For classification, ydata must be an array of integers.")
+    if xt.shape[0] != yt.shape[0]:
+        raise RuntimeError("Different number of datapoints in x and y.")
+    sl = sequence_lengths
+    if sl is not None:
+        if xt.dim() != 3:
+            raise RuntimeError("sequence_lengths supplied for a 2d array.")
+        sl = np.ascontiguousarray(np.asarray(sl).astype(np.int32))
+        if sl.max() > xt.shape[1] or sl.min() < 1:
+            raise RuntimeError("sequence lengths out of range.")
+    if comm.world_size > 1 and not already_sharded:
+        lo, hi = comm.shard_bounds(xt.shape[0])
+        xt, yt = xt[lo:hi], yt[lo:hi]
+        if sl is not None:
+            sl = sl[lo:hi]
+    xt = xt.to(device=device, dtype=torch.float32).contiguous()
+    yt = yt.to(device=device, dtype=torch.int64).contiguous()
+    # [max label, -min label, local row count]: max-reduce the first two, sum the third
+    ext = torch.stack([yt.max(), -yt.min()]).to(torch.float64)
+    comm.all_reduce_max_(ext)
+    count = torch.tensor([float(yt.shape[0])], dtype=torch.float64, device=device)
+    comm.all_reduce_(count)
+    if int(-ext[1].item()) != 0:
+        raise RuntimeError("For classification, there must be a zero category.")
+    return DeviceDataset(xt, yt, sl, chunk_size, 0.0, 1.0, int(round(count.item())), device, comm,
+                         max_class=int(ext[0].item()))

@@ -30,6 +30,12 @@ class Comm:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
+    def all_reduce_max_(self, tensor):
+        """In-place maximum over ranks (dataset statistics only)."""
+        if self.world_size > 1:
+            dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=self.group)
+        return tensor
+
     def barrier(self):
         if self.world_size > 1:
             dist.barrier(group=self.group)

@@ -40,12 +40,25 @@ def single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose):
             print(f"Chunk {j} complete.")
 
 
-def _first_pass(dataset, rank, kernel, random_state, verbose):
+def single_pass_srht(dataset, kernel, compressor, acc_results, verbose):
+    """rand_nys_constructors.py:39-56 (classification: no z^T y)."""
+    for j, (xin, ldata) in enumerate(dataset.get_chunked_x_data()):
+        xdata = kernel.transform_x(xin, ldata)
+        acc_results += compressor.transform_x(xdata).T @ xdata
+        if j % 10 == 0 and verbose:
+            print(f"Chunk {j} complete.")
+
+
+def _first_pass(dataset, rank, kernel, random_state, verbose, is_regression=True):
     comm = dataset.comm
     m = kernel.get_num_rffs()
     acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
-    z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
     compressor = SRHTCompressor(rank, m, device=kernel.device, random_seed=random_state)
+    if not is_regression:
+        single_pass_srht(dataset, kernel, compressor, acc_results, verbose)
+        comm.all_reduce_(acc_results)
+        return acc_results, None, 0, compressor
+    z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
     y_trans_y = single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose)
     comm.all_reduce_(acc_results)
     comm.all_reduce_(z_trans_y)
@@ -53,8 +66,9 @@ def _first_pass(dataset, rank, kernel, random_state, verbose):
     return acc_results, z_trans_y, float(y_trans_y.item()), compressor
 
 
-def initialize_srht(dataset, rank, kernel, random_state, verbose=False):
-    acc_results, z_trans_y, y_trans_y, compressor = _first_pass(dataset, rank, kernel, random_state, verbose)
+def initialize_srht(dataset, rank, kernel, random_state, verbose=False, is_regression=True):
+    acc_results, z_trans_y, y_trans_y, compressor = _first_pass(dataset, rank, kernel, random_state, verbose,
+                                                                is_regression)
     c_mat = compressor.transform_x(acc_results)
     _, c_s1, c_v1 = torch.linalg.svd(c_mat, full_matrices=False)
     mask = c_s1 < 1e-14
@@ -66,9 +80,9 @@ def initialize_srht(dataset, rank, kernel, random_state, verbose=False):
     return u_mat, s_mat, z_trans_y, y_trans_y
 
 
-def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False, n_passes=1):
+def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False, n_passes=1, is_regression=True):
     comm = dataset.comm
-    acc_results, z_trans_y, y_trans_y, _ = _first_pass(dataset, rank, kernel, random_state, verbose)
+    acc_results, z_trans_y, y_trans_y, _ = _first_pass(dataset, rank, kernel, random_state, verbose, is_regression)
     acc_results = acc_results.T.contiguous()
     q_mat = None
     for _ in range(n_passes - 1):
@@ -90,16 +104,17 @@ def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False
 class RandNysPreconditioner:
     """Preconditioner from the randomized Nystrom approximation of (Z^T Z + lambda^2)^-1."""
 
-    def __init__(self, kernel, dataset, max_rank, verbose=False, random_state=123, method="srht"):
+    def __init__(self, kernel, dataset, max_rank, verbose=False, random_state=123, method="srht",
+                 is_regression=True):
         if method not in ["srht_2", "srht_3", "srht"]:
             raise RuntimeError("Unknown method supplied for tuning preconditioner construction.")
         if method.startswith("srht_"):
             n_passes = int(method.split("_")[1])
             self.u_mat, self.eig, self.z_trans_y, self.y_trans_y = initialize_srht_multipass(
-                dataset, max_rank, kernel, random_state, verbose, n_passes)
+                dataset, max_rank, kernel, random_state, verbose, n_passes, is_regression)
         else:
             self.u_mat, self.eig, self.z_trans_y, self.y_trans_y = initialize_srht(
-                dataset, max_rank, kernel, random_state, verbose)
+                dataset, max_rank, kernel, random_state, verbose, is_regression)
         lambda_ = float(kernel.get_lambda())
         min_eig = float(self.eig.min().item())
         self.eig = self.eig + lambda_ ** 2

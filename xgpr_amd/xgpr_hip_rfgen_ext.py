@@ -316,6 +316,32 @@ def hipZCacheBlockMatvec(cacheArr, vecs, outVecs, fitIntercept, workspace, scale
         int(bool(accumulate)), C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
 
 
+def hipZCacheBlockProject(cacheArr, vecs, outArr, fitIntercept, scale=0.0):
+    """``outArr[n, k] = Z @ vecs`` (the classifier's ``xd @ wvec``, nonlinear_cg_toolkit.py:251) on the
+    float64 matrix cores over the float32 feature rows."""
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    v = _dev(vecs, "vecs", torch.float64, 2)
+    o = _dev(outArr, "outArr", torch.float64, 2)
+    if vecs.shape[0] != cacheArr.shape[1] or tuple(outArr.shape) != (cacheArr.shape[0], vecs.shape[1]):
+        raise TypeError("vecs: expected [num_rffs, k]; outArr: expected [n, k]")
+    return _lib.check(_LIB.xgpr_zcache_block_project_f32(
+        zc, v, o, cacheArr.shape[0], cacheArr.shape[1], vecs.shape[1], int(bool(fitIntercept)), float(scale),
+        _stream()))
+
+
+def hipZCacheBlockBackproject(cacheArr, resid, outVecs, fitIntercept, workspace, scale=0.0, accumulate=False):
+    """``outVecs[num_rffs, k] (+)= Z.T @ resid`` (the classifier's gradient sums,
+    nonlinear_cg_toolkit.py:264-269)."""
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    r = _dev(resid, "resid", torch.float64, 2)
+    o = _dev(outVecs, "outVecs", torch.float64, 2)
+    if resid.shape[0] != cacheArr.shape[0] or tuple(outVecs.shape) != (cacheArr.shape[1], resid.shape[1]):
+        raise TypeError("resid: expected [n, k]; outVecs: expected [num_rffs, k]")
+    return _lib.check(_LIB.xgpr_zcache_block_backproject_f32(
+        zc, r, o, cacheArr.shape[0], cacheArr.shape[1], resid.shape[1], int(bool(fitIntercept)), float(scale),
+        int(bool(accumulate)), C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
+
+
 def zcache_block_workspace_bytes(ndatapoints, num_rffs, k):
     return int(_LIB.xgpr_zcache_block_workspace_bytes(ndatapoints, num_rffs, k))
 
