@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # dense FP64 matrix peak: 256 CUs x 4 SIMDs x 2048 flop / 64 cycles x 2.4 GHz
 
 
 def parse():
@@ -225,6 +226,35 @@ def main():
                                "frac": cbytes / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ctraffic,
                                "algorithmic_bytes": cbytes, "kernel_ms": ck_ms},
                   "note": "features generated once (cache_build_s) and streamed; NOT the headline number"}
+        # the block of right-hand sides of the approximate NMLL (k = 26) over the same resident cache: the
+        # two contractions of Z^T (Z V) on the float64 matrix cores (not part of the headline either)
+        if kern.block_ok():
+            from xgpr_amd.kernels import block_workspace_bytes
+            kb = 26
+            vb = torch.randn((m, kb), dtype=torch.float64, device=device)
+            wb = torch.empty_like(vb)
+            bws = torch.empty(block_workspace_bytes(hi - lo, m, kb), dtype=torch.uint8, device=device)
+            for _ in range(2):
+                kern.ztz_block_cached(zc, vb, wb, bws)
+            be0, be1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            breps = 3
+            be0.record()
+            for _ in range(breps):
+                kern.ztz_block_cached(zc, vb, wb, bws)
+            be1.record()
+            torch.cuda.synchronize()
+            b_ms = be0.elapsed_time(be1) / breps
+            bflop = 4.0 * (hi - lo) * m * kb
+            cached["block_matvec_k26"] = {
+                "ms_per_matvec": b_ms,
+                "roofline": {"kernel": "zblock_t_kernel<2,4> + zblock_w_kernel<2> (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                             "achieved": bflop / (b_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": bflop / (b_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "issued": bflop * 32 / kb / (b_ms * 1e-3) / 1e12, "traffic": None,
+                             "algorithmic_flops": bflop},
+                "note": "26 right-hand sides are padded to 32 columns: 'issued' counts the padded MFMA work; "
+                        "MFMA-busy counters in profiles/r1_nmll_block_pmc_mfma.csv"}
+            del vb, wb, bws
         del zc
         ds._zcache = None
         ds._zcache_key = None
