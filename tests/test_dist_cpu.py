@@ -100,3 +100,91 @@ def test_two_rank_cg_equals_single_process_oracle(tmp_path):
     wref, nref, _, _ = orc.cg_fit_lib_internal(okern, ods, 1e-10, 400, None)
     assert int(r0["niter"]) == nref
     assert np.linalg.norm(r0["w"] - wref) <= 1e-9 * np.linalg.norm(wref)
+
+
+# ---- second scenario: the rows next to the path (approximate NMLL with a 2-pass preconditioner; the
+# classifier's cost function) on two ranks.  The SRHT of the preconditioner chunks is a HIP operator too,
+# so the test swaps in an oracle-backed compressor with the product compressor's interface.
+class OracleBackedKernel2(OracleBackedKernel):
+    def transform_x(self, input_x, sequence_length=None):
+        from xgpr_amd.kernels import scale_input
+        xs = scale_input(input_x.to(torch.float32), self.hyperparams[1])
+        return torch.from_numpy(self._features(xs))
+
+    def transform_x_y(self, input_x, input_y, sequence_length=None):
+        return self.transform_x(input_x), input_y.to(torch.float64)
+
+    def fused_ok(self):
+        return False
+
+
+class OracleBackedCompressor:
+    def __init__(self, compression_size, input_size, device="cpu", random_seed=123):
+        from oracle import oracle as orc
+        self.inner = orc.OracleSRHTCompressor(compression_size, input_size, random_seed)
+
+    def transform_x(self, features, no_compression=False):
+        return torch.from_numpy(self.inner.transform_x(features.numpy(), no_compression))
+
+
+def _class_problem():
+    rng = np.random.default_rng(43)
+    n, d, m, ncls = 301, 10, 64, 3
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    y = rng.integers(0, ncls, size=n).astype(np.int64)
+    y[:ncls] = np.arange(ncls)
+    return x, y, m, np.array([0.5, 0.7]), 0.1 * rng.standard_normal((m, ncls))
+
+
+def _worker2(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from xgpr_amd import dist as xd, preconditioner as xp, nmll
+    from xgpr_amd.dataset import build_regression_dataset, build_classification_dataset
+    from xgpr_amd.classification import NonlinearCGClassification
+    xp.SRHTCompressor = OracleBackedCompressor
+    comm = xd.init_from_env(device_type="cpu")
+    x, y, m, hp = _problem()
+    ds = build_regression_dataset(x, y, chunk_size=100, device="cpu", comm=comm)
+    kern = OracleBackedKernel2(m, x.shape[1], hp)
+    pre = xp.RandNysPreconditioner(kern, ds, 32, False, 123, "srht_2")
+    det = {}
+    val = nmll.approximate_nmll(kern, ds, pre, {"nsamples": 5, "nmll_iter": 200, "nmll_tol": 1e-8}, 123,
+                                cache_features=False, details=det)
+    xc, yc, mc, hpc, w0 = _class_problem()
+    cds = build_classification_dataset(xc, yc, chunk_size=64, device="cpu", comm=comm)
+    assert cds.get_n_classes() == 3 and cds.get_ndatapoints() == xc.shape[0]
+    ckern = OracleBackedKernel2(mc, xc.shape[1], hpc)
+    grad, loss = NonlinearCGClassification(cds, ckern, False, None, cache_features=False) \
+        .cost_fun_classification(torch.from_numpy(w0))
+    np.savez(os.path.join(outdir, f"s2_rank{rank}.npz"), nmll=val, logdet=det["logdet"], ratio=pre.achieved_ratio,
+             grad=grad.numpy(), loss=loss)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_nmll_and_classifier_cost_equal_single_process_oracle(tmp_path):
+    from oracle import oracle as orc
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker2, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "s2_rank0.npz"), np.load(tmp_path / "s2_rank1.npz")
+    assert float(r0["nmll"]) == float(r1["nmll"]) and np.array_equal(r0["grad"], r1["grad"])
+    x, y, m, hp = _problem()
+    ods = orc.OracleDataset(x.astype(np.float64), y, chunk_size=100)
+    okern = orc.OracleKernel("RBF", m, x.shape, hp, 123)
+    opre = orc.OracleRandNysPreconditioner(okern, ods, 32, 123, "srht_2")
+    assert np.isclose(float(r0["ratio"]), opre.achieved_ratio, rtol=1e-6)
+    det = {}
+    ref = orc.approximate_nmll(okern, ods, opre, 5, 200, 1e-8, 123, details=det)
+    assert np.isclose(float(r0["logdet"]), det["logdet"], rtol=1e-7)
+    assert np.isclose(float(r0["nmll"]), ref, rtol=1e-8)
+    xc, yc, mc, hpc, w0 = _class_problem()
+    cds = orc.OracleClassificationDataset(xc.astype(np.float64), yc, chunk_size=64)
+    ckern = orc.OracleKernel("RBF", mc, xc.shape, hpc, 123)
+    gref, lref = orc.classification_cost(cds, ckern, w0)
+    assert np.isclose(float(r0["loss"]), lref, rtol=1e-10)
+    assert np.linalg.norm(r0["grad"] - gref) <= 1e-10 * np.linalg.norm(gref)

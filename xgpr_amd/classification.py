@@ -75,6 +75,19 @@ class NonlinearCGClassification:
         wvec = wvec.contiguous()
         grad = torch.zeros_like(wvec)
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        if not (wvec.is_cuda and hasattr(self.kernel, "block_ok") and self.kernel.block_ok()):
+            # num_rffs not a multiple of 4: float64 feature chunks and library GEMMs, as the reference does
+            for xd, yd, ld in self.dataset.get_chunked_data():
+                z = self.kernel.transform_x(xd, ld)
+                pred = z @ wvec
+                pred -= pred.max(dim=1, keepdim=True).values
+                pred = 2.71828 ** pred
+                pred /= pred.sum(dim=1, keepdim=True)
+                idx = yd.to(torch.int64)
+                loss -= torch.log(pred.clamp(min=1e-16)).gather(1, idx[:, None]).sum()
+                pred.scatter_add_(1, idx[:, None], torch.full((z.shape[0], 1), -1.0, dtype=torch.float64, device=dev))
+                grad += z.T @ pred
+            return self._finish_cost(grad, loss, wvec)
         icpt, scale = self._block_args()
         for zc, labels in self._windows():
             n = zc.shape[0]
@@ -106,6 +119,9 @@ class NonlinearCGClassification:
                     ext.hipZCacheBlockBackproject(zc, pred[:, j0:j1].contiguous(), g, icpt, self._ws, scale,
                                                   accumulate=True)
                     grad[:, j0:j1] = g
+        return self._finish_cost(grad, loss, wvec)
+
+    def _finish_cost(self, grad, loss, wvec):
         comm = self.dataset.comm
         comm.all_reduce_(grad)
         comm.all_reduce_(loss)
