@@ -205,6 +205,23 @@ int xgpr_zcache_matvec_f32(const float *zc, const double *v, double *w_out, long
 int xgpr_zcache_matvec_scaled_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs,
                                   double scale, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- cudaMiniARDGrad(inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gradArr, fitIntercept)
+ * (gpu_rf_gen/xgpr_cuda_rfgen_cpp_ext.cpp:50-60; cpu_rf_gen/rbf_ops/ard_ops.cpp:39-124): MiniARD random
+ * features out[n, num_rffs] and their gradient grad[n, num_rffs, num_lengthscales] w.r.t. the per-group
+ * inverse lengthscales, from the dense precomputed weights[num_freqs, d]; sigma_map[d] int32 (group of each
+ * input feature), sigma_vals[d] float64, all on the device.  fit_intercept only selects the constant; the
+ * caller sets column 0 (kernel_baseclass.py:356-359).  Up to 8 groups; n <= 262140 per call. */
+int xgpr_mini_ard_grad_f32(const float *x, double *out, const float *weights, const int32_t *sigma_map,
+                           const double *sigma_vals, double *grad, long n, long d, long out_rows,
+                           long num_rffs, long num_freqs, long w_cols, long map_len, long sig_len,
+                           long grad_rows, long grad_cols, long num_lengthscales, int fit_intercept,
+                           void *stream);
+int xgpr_mini_ard_grad_f64(const double *x, double *out, const double *weights, const int32_t *sigma_map,
+                           const double *sigma_vals, double *grad, long n, long d, long out_rows,
+                           long num_rffs, long num_freqs, long w_cols, long map_len, long sig_len,
+                           long grad_rows, long grad_cols, long num_lengthscales, int fit_intercept,
+                           void *stream);
+
 /* ---- Block matvec over the resident cache for k right-hand sides, the matrix-core part of the
  * CG path: replaces `matvec += Z.T @ (Z @ vec)` of GPU_ConjugateGrad._matvec for vec of shape
  * [M, k] (fitting_toolkit/cg_tools.py:41-44; k = nsamples + 1 = 26 in approximate_nmll,

@@ -139,6 +139,23 @@ class Oracle:
                           C.c_long(radem.shape[2]), C.c_double(float(sigma)),
                           C.c_int(bool(fitIntercept)))
 
+    def cpuMiniARDGrad(self, inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gradArr, fitIntercept):
+        s = _suffix(inputArr)
+        _check(inputArr, inputArr.dtype, 2, "inputArr")
+        _check(outputArr, np.float64, 2, "outputArr")
+        _check(precompWeights, inputArr.dtype, 2, "precompWeights")
+        _check(sigmaMap, np.int32, 1, "sigmaMap")
+        _check(sigmaVals, np.float64, 1, "sigmaVals")
+        _check(gradArr, np.float64, 3, "gradArr")
+        return self._call(f"orc_mini_ard_grad_{s}", _ptr(inputArr), _ptr(outputArr), _ptr(precompWeights),
+                          _ptr(sigmaMap), _ptr(sigmaVals), _ptr(gradArr), C.c_long(inputArr.shape[0]),
+                          C.c_long(inputArr.shape[1]), C.c_long(outputArr.shape[0]),
+                          C.c_long(outputArr.shape[1]), C.c_long(precompWeights.shape[0]),
+                          C.c_long(precompWeights.shape[1]), C.c_long(sigmaMap.shape[0]),
+                          C.c_long(sigmaVals.shape[0]), C.c_long(gradArr.shape[0]),
+                          C.c_long(gradArr.shape[1]), C.c_long(gradArr.shape[2]),
+                          C.c_int(bool(fitIntercept)))
+
     def cpuConv1dFGen(self, inputArr, outputArr, radem, chiArr, seqlengths, convWidth, scalingType):
         s = _suffix(inputArr)
         _check(inputArr, inputArr.dtype, 3, "inputArr")
@@ -378,6 +395,86 @@ class OracleKernel:
         else:
             self.ops.cpuRBFGrad(xin, out, grad, self.radem_diag, self.chi_arr,
                                 self.hyperparams[1], self.fit_intercept)
+        if self.fit_intercept:
+            out[:, 0] = 1.
+            grad[:, 0, :] = 0.
+        return out, grad
+
+
+class OracleMiniARDKernel:
+    """kernels/ARD_kernels/mini_ard.py:16-287: one inverse lengthscale per group of input features.
+    Features: the input scaled per feature, then the SORF operator (:171-194); gradient: dense
+    precomputed weights (three FHT rounds applied to the identity, :196-238) through
+    cpuMiniARDGrad (:240-275)."""
+
+    def __init__(self, num_rffs, xdim, split_points, hyperparams=None, random_seed=123,
+                 double_precision=False, fit_intercept=True, ops=None):
+        self.ops = ops if ops is not None else Oracle()
+        self.num_rffs, self.num_freqs = num_rffs, num_rffs // 2
+        self.fit_intercept = fit_intercept
+        self.double_precision = double_precision
+        self.xdim = tuple(xdim)
+        self.split_pts = np.sort([0] + list(split_points) + [xdim[1]])
+        self.hyperparams = np.ones((self.split_pts.shape[0])) if hyperparams is None \
+            else np.asarray(hyperparams, dtype=np.float64)
+        self.padded_dims = padded_dims(xdim[-1])
+        self.nblocks = ceil(self.num_freqs / self.padded_dims) if self.padded_dims < self.num_freqs else 1
+        rng = np.random.default_rng(random_seed)
+        self.radem_diag = rng.choice(np.asarray([-1, 1], dtype=np.int8),
+                                     size=(3, 1, self.nblocks * self.padded_dims), replace=True)
+        from scipy.stats import chi as _chi
+        self.chi_arr = _chi.rvs(df=self.padded_dims, size=self.num_freqs, random_state=random_seed)
+        if not double_precision:
+            self.chi_arr = self.chi_arr.astype(np.float32)
+        self.full_ard_weights = np.zeros((xdim[-1]))
+        self.ard_position_key = np.zeros((xdim[-1]), dtype=np.int32)
+        for i in range(1, self.split_pts.shape[0]):
+            self.full_ard_weights[self.split_pts[i - 1]:self.split_pts[i]] = self.hyperparams[i]
+            self.ard_position_key[self.split_pts[i - 1]:self.split_pts[i]] = i - 1
+        self.precomputed_weights = None
+
+    def get_lambda(self):
+        return self.hyperparams[0]
+
+    def get_num_rffs(self):
+        return self.num_rffs
+
+    def transform_x(self, input_x, sequence_length=None):
+        xtrans = input_x * self.full_ard_weights[None, :]
+        xtrans = np.ascontiguousarray(xtrans.astype(np.float64 if self.double_precision else np.float32))
+        out = np.zeros((input_x.shape[0], self.num_rffs), np.float64)
+        self.ops.cpuRBFFeatureGen(xtrans, out, self.radem_diag, self.chi_arr, self.fit_intercept)
+        if self.fit_intercept:
+            out[:, 0] = 1.
+        return out
+
+    def precompute_weights(self):
+        nc = 1.0 / (2.0 ** (np.log2(self.padded_dims) / 2.0))
+        padded_chi = np.zeros((self.nblocks * self.padded_dims))
+        padded_chi[:self.chi_arr.shape[0]] = self.chi_arr
+        blocks = []
+        for i in range(self.nblocks):
+            ident = np.eye(self.padded_dims)
+            lo, hi = i * self.padded_dims, (i + 1) * self.padded_dims
+            for r in range(3):
+                ident *= self.radem_diag[r:r + 1, 0, lo:hi] * nc
+                self.ops.cpuFastHadamardTransform2D(ident)
+            ident *= padded_chi[lo:hi]
+            blocks.append(ident.T[:, :self.xdim[-1]])
+        w = np.vstack(blocks)[:self.num_freqs, :]
+        if not self.double_precision:
+            w = w.astype(np.float32)
+        self.precomputed_weights = np.ascontiguousarray(w)
+
+    def gradient_x(self, input_x, sequence_length=None):
+        if self.precomputed_weights is None:
+            self.precompute_weights()
+        xin = np.ascontiguousarray(input_x.astype(np.float64 if self.double_precision else np.float32))
+        nl = int(self.ard_position_key.max()) + 1
+        out = np.zeros((xin.shape[0], self.num_rffs), np.float64)
+        grad = np.zeros((xin.shape[0], self.num_rffs, nl), np.float64)
+        self.ops.cpuMiniARDGrad(xin, out, self.precomputed_weights, self.ard_position_key,
+                                self.full_ard_weights, grad, self.fit_intercept)
         if self.fit_intercept:
             out[:, 0] = 1.
             grad[:, 0, :] = 0.

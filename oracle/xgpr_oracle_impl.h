@@ -195,6 +195,53 @@ int FN(orc_rbf_grad)(const T *x, double *out, double *grad, const int8_t *radem,
     return 0;
 }
 
+/* rbf_ops/ard_ops.cpp:39-124 (ardGrad_): random features AND their gradient w.r.t. the
+ * per-group lengthscales of the MiniARD kernel from a dense precomputed weight matrix
+ * (num_freqs x d).  The product x[k] * w[j,k] is formed in T and widened (:100); the
+ * group sums, the projection and cos/sin are double; the constant is typed T (:86-91).
+ * The op only chooses the constant with fit_intercept -- column 0 is set by the Python
+ * caller (kernel_baseclass.py:356-359).  Codes: -1 "no datapoints", -4 "Wrong array sizes.". */
+int FN(orc_mini_ard_grad)(const T *x, double *out, const T *weights,
+                          const int32_t *sigma_map, const double *sigma_vals,
+                          double *grad, long n, long d, long out_rows, long num_rffs,
+                          long num_freqs, long w_cols, long map_len, long sig_len,
+                          long grad_rows, long grad_cols, long num_lengthscales,
+                          int fit_intercept)
+{
+    if (n == 0 || out_rows != n) return -1;
+    if (grad_rows != out_rows || grad_cols != num_rffs) return -4;
+    if (w_cols != d) return -4;
+    if (num_rffs != 2 * num_freqs || map_len != w_cols) return -4;
+    if (sig_len != map_len) return -4;
+    T norm;
+    if (fit_intercept) norm = (T)sqrt(1.0 / ((double)num_freqs - 0.5));
+    else               norm = (T)sqrt(1.0 / (double)num_freqs);
+    long nl = num_lengthscales;
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) {
+        const T *xi = x + i * d;
+        for (long j = 0; j < num_freqs; j++) {
+            double *g = grad + (i * num_rffs + 2 * j) * nl;
+            const T *w = weights + j * d;
+            double rf = 0;
+            for (long k = 0; k < d; k++) {
+                double dot = xi[k] * w[k];
+                g[sigma_map[k]] += dot;
+                rf += sigma_vals[k] * dot;
+            }
+            double c = norm * cos(rf), sn = norm * sin(rf);
+            out[i * num_rffs + 2 * j] = c;
+            out[i * num_rffs + 2 * j + 1] = sn;
+            for (long k = 0; k < nl; k++) {
+                double gv = g[k];
+                g[k] = -gv * sn;
+                g[k + nl] = gv * c;
+            }
+        }
+    }
+    return 0;
+}
+
 /* Sequence-length validation shared by the conv ops:
  * convolution_ops/rbf_convolution.cpp:55-82, conv1d_operations.cpp:52-81.
  *   -5 "wrong array sizes", -6 "invalid conv_width",

@@ -466,6 +466,54 @@ def g11_classifier(xgpr):
          weights=np.asarray(mod.weights), probs=probs)
 
 
+def g12_mini_ard(xgpr):
+    """MiniARD: the reference's OWN ground truth for cpu/cudaMiniARDGrad, built as in its
+    tests/fht_operations_tests/test_ARD_kernel_gradient.py:120-162 from two routes that do not involve the
+    gradient operator: features from MiniARD.transform_x (per-feature scaling + the SORF operator on the
+    compiled reference core) and the gradient from an einsum with MiniARD.precompute_weights() (three FHT
+    rounds on the identity).  Settings are the test's (:22-38), trimmed to a few rows / frequencies."""
+    from xGPR.kernels.ARD_kernels.mini_ard import MiniARD
+    out = {}
+    cases = [((6, 50), 128, [25], False), ((6, 50), 128, [25], True), ((5, 232), 96, [100, 200], False),
+             ((3, 2049), 48, [30, 450], True)]
+    for ci, (xdim, num_freqs, split_points, icpt) in enumerate(cases):
+        rng = np.random.default_rng(123)
+        x = rng.uniform(low=-10.0, high=10.0, size=xdim)
+        hp = np.array([1.0] + [0.02 + 0.01 * i for i in range(len(split_points) + 1)])   # lambda, inverse lengthscales
+
+        def build(intercept):
+            k = MiniARD(xdim, 2 * num_freqs, 123, device="cpu", double_precision=True,
+                        kernel_spec_parms={"split_points": split_points, "intercept": intercept})
+            k.set_hyperparams(hp, logspace=False)
+            k.precompute_weights()
+            return k
+        kernel, nik = build(icpt), build(False)
+        xtrans = kernel.transform_x(x)
+        pw = kernel.precomputed_weights.copy()
+        if icpt:
+            xtrans[:, 0] = nik.transform_x(x)[:, 0]
+            xtrans[:, 0] /= np.sqrt(2 / (pw.shape[0]))
+            xtrans[:, 0] *= np.sqrt(2 / (pw.shape[0] - 0.5))
+        grad = np.zeros((xtrans.shape[0], xtrans.shape[1], len(split_points) + 1))
+        ks = kernel.split_pts
+        for i in range(ks.shape[0] - 1):
+            tmp = np.einsum("ij,kj->ki", pw[:, ks[i]:ks[i + 1]], x[:, ks[i]:ks[i + 1]])
+            for j in range(pw.shape[0]):
+                grad[:, 2 * j, i] = -tmp[:, j] * xtrans[:, 2 * j + 1]
+                grad[:, 2 * j + 1, i] = tmp[:, j] * xtrans[:, 2 * j]
+        out[f"c{ci}_x"] = x
+        out[f"c{ci}_num_freqs"] = np.int64(num_freqs)
+        out[f"c{ci}_split_points"] = np.asarray(split_points, dtype=np.int64)
+        out[f"c{ci}_intercept"] = np.bool_(icpt)
+        out[f"c{ci}_hyperparams"] = hp
+        out[f"c{ci}_features"] = xtrans          # column 0 is the un-overwritten cos feature (see the test's note)
+        out[f"c{ci}_grad"] = grad
+        out[f"c{ci}_weights"] = pw
+        out[f"c{ci}_transform_x"] = kernel.transform_x(x)
+    out["ncases"] = np.int64(len(cases))
+    save("g12_mini_ard.npz", **out)
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -479,3 +527,4 @@ if __name__ == "__main__":
     g9_exact(xgpr)
     g10_nmll(xgpr)
     g11_classifier(xgpr)
+    g12_mini_ard(xgpr)

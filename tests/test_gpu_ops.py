@@ -341,3 +341,52 @@ def test_conv_grad_vs_oracle(ext, oracle, L, C, cw, rffs, sc, n):
     ext.hipConvGrad(dev(x), o, dev(radem), dev(chi), sl, g, sigma, cw, sc)
     assert np.abs(o.cpu().numpy() - ro).max() <= 1e-6 * np.abs(ro).max()
     assert np.abs(g.cpu().numpy() - rg).max() <= 1e-6 * np.abs(rg).max()
+
+
+def test_g12_mini_ard_grad_and_kernel_vs_reference_ground_truth(oracle):
+    """cudaMiniARDGrad drop-in (hipMiniARDGrad) and the MiniARD kernel object against the reference's own
+    ground truth (tests/golden/g12_mini_ard.npz, reference test_ARD_kernel_gradient.py:120-162) with the
+    tolerances of that test (:77-80), and against the oracle's operator on the same inputs."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel, MiniARDKernel
+    g = load_golden("g12_mini_ard.npz")
+    for ci in range(int(g["ncases"])):
+        x = g[f"c{ci}_x"]
+        nf, icpt = int(g[f"c{ci}_num_freqs"]), bool(g[f"c{ci}_intercept"])
+        sp = [int(v) for v in g[f"c{ci}_split_points"]]
+        for dp, rtol_f, atol_f, rtol_g, atol_g in ((True, 1e-5, 1e-8, 1e-5, 1e-8), (False, 1e-5, 1e-5, 1e-4, 1e-3)):
+            kern = MiniARDKernel(x.shape, 2 * nf, 123, DEV, dp, {"split_points": sp, "intercept": icpt})
+            kern.set_hyperparams(g[f"c{ci}_hyperparams"], logspace=False)
+            kern.precompute_weights()
+            okern = orc.OracleMiniARDKernel(2 * nf, x.shape, sp, g[f"c{ci}_hyperparams"], 123,
+                                            double_precision=dp, fit_intercept=icpt, ops=oracle)
+            okern.precompute_weights()
+            # FHT on the identity is exact integer arithmetic until the chi multiply: weights are bit-identical
+            assert np.array_equal(kern.precomputed_weights.cpu().numpy(), okern.precomputed_weights)
+            feats, grad = kern.gradient_x(x)
+            ofeats, ograd = okern.gradient_x(x)
+            assert np.allclose(feats.cpu().numpy(), ofeats, rtol=1e-9, atol=1e-11)     # cos/sin of a float64 argument
+            assert np.allclose(grad.cpu().numpy(), ograd, rtol=1e-9, atol=1e-9)
+            ref_f, ref_g = g[f"c{ci}_features"].copy(), g[f"c{ci}_grad"].copy()
+            if icpt:
+                ref_g[:, 0, :] = 0
+                ref_f[:, 0] = 1.0
+            assert np.allclose(feats.cpu().numpy(), ref_f, rtol=rtol_f, atol=atol_f)
+            assert np.allclose(grad.cpu().numpy(), ref_g, rtol=rtol_g, atol=atol_g)
+            if dp:
+                assert np.allclose(kern.transform_x(x).cpu().numpy(), g[f"c{ci}_transform_x"], rtol=1e-6, atol=1e-7)
+    assert isinstance(make_kernel("MiniARD", (10, 20), 64, 123, DEV, {"split_points": [5]}), MiniARDKernel)
+    with pytest.raises(ValueError):
+        make_kernel("MiniARD", (10, 20), 64, 123, DEV, {})
+    # validation mirrors the reference's throws (ard_ops.cpp:68-84)
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    xt = torch.zeros((4, 6), dtype=torch.float32, device=DEV)
+    w = torch.zeros((8, 6), dtype=torch.float32, device=DEV)
+    mp = torch.zeros(6, dtype=torch.int32, device=DEV)
+    sv = torch.ones(6, dtype=torch.float64, device=DEV)
+    with pytest.raises(RuntimeError):
+        ext.hipMiniARDGrad(xt, torch.zeros((4, 14), dtype=torch.float64, device=DEV), w, mp, sv,
+                           torch.zeros((4, 14, 1), dtype=torch.float64, device=DEV), True)
+    with pytest.raises(RuntimeError):
+        ext.hipMiniARDGrad(xt, torch.zeros((4, 16), dtype=torch.float64, device=DEV), w, mp[:5], sv,
+                           torch.zeros((4, 16, 1), dtype=torch.float64, device=DEV), True)

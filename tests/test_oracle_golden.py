@@ -268,3 +268,27 @@ def test_g11_classifier_oracle_vs_reference(oracle):
     probs = orc.predict_proba(kern, w, g["xtest"])
     assert np.allclose(probs, g["probs"], rtol=1e-5, atol=1e-7)
     assert (probs.argmax(axis=1) == g["ytest"]).mean() > 0.9
+
+
+def test_g12_mini_ard_oracle_vs_reference_ground_truth(oracle):
+    """cpuMiniARDGrad (reference rbf_ops/ard_ops.cpp:39-124) and the MiniARD host logic
+    (kernels/ARD_kernels/mini_ard.py) against the reference's own ground truth, which reaches the same
+    features and gradient without the gradient operator (its test_ARD_kernel_gradient.py:120-162)."""
+    g = load_golden("g12_mini_ard.npz")
+    for ci in range(int(g["ncases"])):
+        x = g[f"c{ci}_x"]
+        nf, icpt = int(g[f"c{ci}_num_freqs"]), bool(g[f"c{ci}_intercept"])
+        for dp, rtol_f, atol_f, rtol_g, atol_g in ((True, 1e-5, 1e-8, 1e-5, 1e-8), (False, 1e-5, 1e-5, 1e-4, 1e-3)):
+            kern = orc.OracleMiniARDKernel(2 * nf, x.shape, list(g[f"c{ci}_split_points"]), g[f"c{ci}_hyperparams"],
+                                           123, double_precision=dp, fit_intercept=icpt, ops=oracle)
+            kern.precompute_weights()
+            if dp:
+                assert np.allclose(kern.precomputed_weights, g[f"c{ci}_weights"], rtol=1e-12, atol=1e-14)
+                assert np.allclose(kern.transform_x(x), g[f"c{ci}_transform_x"], rtol=1e-9, atol=1e-12)
+            feats, grad = kern.gradient_x(x)
+            ref_f, ref_g = g[f"c{ci}_features"].copy(), g[f"c{ci}_grad"].copy()
+            if icpt:                       # as the reference's test does (:158-160)
+                ref_g[:, 0, :] = 0
+                ref_f[:, 0] = 1.0
+            assert np.allclose(feats, ref_f, rtol=rtol_f, atol=atol_f)     # tolerances of the reference's test (:77-80)
+            assert np.allclose(grad, ref_g, rtol=rtol_g, atol=atol_g)

@@ -23,6 +23,8 @@ SIGNATURES = {
     "xgpr_rbf_feature_gen_f64": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_rbf_grad_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _vp, _sz, _vp],
     "xgpr_rbf_grad_f64": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _vp, _sz, _vp],
+    "xgpr_mini_ard_grad_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _l, _l, _l, _i, _vp],
+    "xgpr_mini_ard_grad_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _l, _l, _l, _i, _vp],
     "xgpr_conv1d_fgen_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _i, _vp, _sz, _vp],
     "xgpr_conv1d_fgen_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _i, _vp, _sz, _vp],
     "xgpr_conv_grad_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _i,

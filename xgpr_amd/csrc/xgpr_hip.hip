@@ -1425,6 +1425,74 @@ __global__ __launch_bounds__(256) void reduce_block_slabs_kernel(const double *_
 }
 
 // ------------------------------------------------------------------------------------
+// MiniARD features + gradient (cudaMiniARDGrad; rbf_ops/ard_ops.cpp:39-124, ard_ops.cu): a dense
+// projection with a precomputed [num_freqs, d] weight matrix, the product x[k] w[j,k] grouped by
+// lengthscale.  Not part of the SORF path -- it completes the operator surface.  Workgroup =
+// 64 frequencies x 4 datapoints; weights and inputs go through LDS in 64-wide slices of d so that
+// the global reads are coalesced along d; the per-(datapoint, frequency) sums run in k order, as in
+// the reference (x * w in T, everything after in float64).
+// ------------------------------------------------------------------------------------
+constexpr int ARD_MAX_GROUPS = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void mini_ard_grad_kernel(const T *__restrict__ x, double *out,
+                                                            const T *__restrict__ weights,
+                                                            const int32_t *__restrict__ sigma_map,
+                                                            const double *__restrict__ sigma_vals, double *grad,
+                                                            long n, long d, long F, int nl, double norm) {
+    __shared__ T ws[64][65];
+    __shared__ T xs[4][64];
+    __shared__ int32_t ms[64];
+    __shared__ double ss[64];
+    const int fj = threadIdx.x & 63, ri = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + fj;
+    const long i = (long)blockIdx.y * 4 + ri;
+    double g[ARD_MAX_GROUPS];
+    #pragma unroll
+    for (int l = 0; l < ARD_MAX_GROUPS; l++) g[l] = 0.0;
+    double rf = 0.0;
+    for (long k0 = 0; k0 < d; k0 += 64) {
+        // stage: lane fj walks d (coalesced), 16 weight rows per pass of the 4 thread rows
+        #pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int jr = 4 * p + ri;
+            const long jj = (long)blockIdx.x * 64 + jr;
+            ws[jr][fj] = (jj < F && k0 + fj < d) ? weights[jj * d + k0 + fj] : (T)0;
+        }
+        xs[ri][fj] = (i < n && k0 + fj < d) ? x[i * d + k0 + fj] : (T)0;
+        if (ri == 0) {
+            ms[fj] = k0 + fj < d ? sigma_map[k0 + fj] : 0;
+            ss[fj] = k0 + fj < d ? sigma_vals[k0 + fj] : 0.0;
+        }
+        __syncthreads();
+        const int kmax = (int)(d - k0 < 64 ? d - k0 : 64);
+        for (int k = 0; k < kmax; k++) {
+            const double dot = (double)(xs[ri][k] * ws[fj][k]);
+            const int grp = ms[k];
+            #pragma unroll
+            for (int l = 0; l < ARD_MAX_GROUPS; l++) g[l] += (grp == l) ? dot : 0.0;
+            rf += ss[k] * dot;
+        }
+        __syncthreads();
+    }
+    if (i >= n || j >= F) return;
+    double sn, cs;
+    sincos(rf, &sn, &cs);
+    cs *= norm;
+    sn *= norm;
+    out[i * 2 * F + 2 * j] = cs;
+    out[i * 2 * F + 2 * j + 1] = sn;
+    double *gp = grad + (i * 2 * F + 2 * j) * nl;
+    #pragma unroll
+    for (int l = 0; l < ARD_MAX_GROUPS; l++) {
+        if (l < nl) {
+            gp[l] = -g[l] * sn;
+            gp[l + nl] = g[l] * cs;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // CG vector updates for one right-hand side (fitting_toolkit/cg_tools.py:255-274), fused into
 // two single-workgroup kernels: M is only 10^3..10^5, so one workgroup reduces and updates the
 // whole vector in a few microseconds, deterministically, instead of ~20 library launches.
@@ -2103,6 +2171,28 @@ int zcache_block_impl(int mode, const float *zc, const double *in, double *out, 
     return 0;
 }
 
+template <typename T>
+int mini_ard_impl(const T *x, double *out, const T *weights, const int32_t *sigma_map, const double *sigma_vals,
+                  double *grad, long n, long d, long out_rows, long num_rffs, long num_freqs, long w_cols, long map_len,
+                  long sig_len, long grad_rows, long grad_cols, long num_lengthscales, int fit_intercept, void *stream) {
+    if (n == 0 || out_rows != n) return fail(XGPR_ERR_NO_DATAPOINTS, "no datapoints");
+    if (grad_rows != out_rows || grad_cols != num_rffs) return fail(XGPR_ERR_ARRAY_SIZES, "Wrong array sizes.");
+    if (w_cols != d) return fail(XGPR_ERR_ARRAY_SIZES, "Wrong array sizes.");
+    if (num_rffs != 2 * num_freqs || map_len != w_cols) return fail(XGPR_ERR_ARRAY_SIZES, "Wrong array sizes.");
+    if (sig_len != map_len) return fail(XGPR_ERR_ARRAY_SIZES, "Wrong array sizes.");
+    if (num_lengthscales < 1 || num_lengthscales > ARD_MAX_GROUPS)
+        return fail(XGPR_ERR_UNSUPPORTED, "MiniARD gradient supports up to 8 lengthscale groups");
+    const long yblocks = (n + 3) / 4;
+    if (yblocks > 65535) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch (chunk the input)");
+    // the constant is typed T in the reference (ard_ops.cpp:86-91)
+    const double norm = (double)(T)std::sqrt(1.0 / (fit_intercept ? (double)num_freqs - 0.5 : (double)num_freqs));
+    hipLaunchKernelGGL(mini_ard_grad_kernel<T>, dim3((unsigned)((num_freqs + 63) / 64), (unsigned)yblocks), dim3(256), 0,
+                       (hipStream_t)stream, x, out, weights, sigma_map, sigma_vals, grad, n, d, num_freqs,
+                       (int)num_lengthscales, norm);
+    HIP_TRY(hipGetLastError(), "mini_ard_grad_kernel launch");
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -2155,6 +2245,21 @@ int xgpr_rbf_grad_f64(const double *x, double *out, double *grad, const int8_t *
                       void *stream) {
     return rbf_impl<double>(x, out, grad, radem, chi, n, d, out_rows, num_rffs, grad_rows, grad_cols, num_freqs,
                             radem_shape2, sigma, fit_intercept, true, workspace, workspace_bytes, stream);
+}
+
+int xgpr_mini_ard_grad_f32(const float *x, double *out, const float *weights, const int32_t *sigma_map,
+                           const double *sigma_vals, double *grad, long n, long d, long out_rows, long num_rffs,
+                           long num_freqs, long w_cols, long map_len, long sig_len, long grad_rows, long grad_cols,
+                           long num_lengthscales, int fit_intercept, void *stream) {
+    return mini_ard_impl<float>(x, out, weights, sigma_map, sigma_vals, grad, n, d, out_rows, num_rffs, num_freqs, w_cols,
+                                map_len, sig_len, grad_rows, grad_cols, num_lengthscales, fit_intercept, stream);
+}
+int xgpr_mini_ard_grad_f64(const double *x, double *out, const double *weights, const int32_t *sigma_map,
+                           const double *sigma_vals, double *grad, long n, long d, long out_rows, long num_rffs,
+                           long num_freqs, long w_cols, long map_len, long sig_len, long grad_rows, long grad_cols,
+                           long num_lengthscales, int fit_intercept, void *stream) {
+    return mini_ard_impl<double>(x, out, weights, sigma_map, sigma_vals, grad, n, d, out_rows, num_rffs, num_freqs, w_cols,
+                                 map_len, sig_len, grad_rows, grad_cols, num_lengthscales, fit_intercept, stream);
 }
 
 int xgpr_conv1d_fgen_f32(const float *x, double *out, const int8_t *radem, const float *chi,

@@ -327,6 +327,124 @@ class ConvSORFKernel(KernelBase):
         return xtrans
 
 
+class MiniARDKernel(KernelBase):
+    """kernels/ARD_kernels/mini_ard.py:16-287: an RBF kernel with one inverse lengthscale per group of
+    input features (groups delimited by ``split_points``).  hyperparams = [lambda, sigma_1 .. sigma_G].
+    Features: input scaled per feature, then the SORF operator; gradient: dense precomputed weights
+    (three FHT rounds on the identity, built on the device with hipFastHadamardTransform2D in float64)
+    through hipMiniARDGrad."""
+
+    def __init__(self, xdim, num_rffs, random_seed=123, device="cuda", double_precision=False,
+                 kernel_spec_parms=None):
+        kernel_spec_parms = kernel_spec_parms or {}
+        super().__init__(num_rffs, xdim, kernel_spec_parms, device)
+        self.double_precision = double_precision
+        if len(self._xdim) != 2:
+            raise ValueError("The dimensionality of the input is inappropriate for "
+                             "the kernel you have selected.")
+        if "split_points" not in kernel_spec_parms:
+            raise ValueError("For the MiniARD kernel, 'kernel_specific_params' "
+                             "must contain a list called 'split_points'.")
+        if not isinstance(kernel_spec_parms["split_points"], list):
+            raise ValueError("For the MiniARD kernel, 'split_points' must be a list.")
+        self.kernel_choice = "MiniARD"
+        self.split_pts = np.sort([0] + kernel_spec_parms["split_points"] + [xdim[1]])
+        self._check_split_points(xdim)
+        self.hyperparams = np.ones((self.split_pts.shape[0]))
+        self.padded_dims = padded_dims(xdim[-1])
+        radem_array = np.asarray([-1, 1], dtype=np.int8)
+        rng = np.random.default_rng(random_seed)
+        self.nblocks = ceil(self.num_freqs / self.padded_dims) if self.padded_dims < self.num_freqs else 1
+        radem = rng.choice(radem_array, size=(3, 1, self.nblocks * self.padded_dims), replace=True)
+        chi_arr = _chi.rvs(df=self.padded_dims, size=self.num_freqs, random_state=random_seed)
+        if not double_precision:
+            chi_arr = chi_arr.astype(np.float32)
+        self._to_device(radem, chi_arr)
+        self.precomputed_weights = None
+        self._set_ard_arrays()
+
+    def _check_split_points(self, xdim):
+        """mini_ard.py:113-133."""
+        if self.split_pts.shape[0] - 2 < 1:
+            raise ValueError("There must be at least one split point to use MiniARD.")
+        if self.split_pts[0] < 0:
+            raise ValueError("The first split point must be > 0.")
+        if self.split_pts[-1] > xdim[1]:
+            raise ValueError("The last split point must be < shape[1] of the input data.")
+        if np.diff(self.split_pts).min() == 0:
+            raise ValueError("At least two of the split points supplied are identical.")
+
+    def _set_ard_arrays(self):
+        """mini_ard.py:158-168 (kernel_specific_set_hyperparams)."""
+        full = np.zeros((self._xdim[-1]))
+        key = np.zeros((self._xdim[-1]), dtype=np.int32)
+        for i in range(1, self.split_pts.shape[0]):
+            full[self.split_pts[i - 1]:self.split_pts[i]] = self.hyperparams[i]
+            key[self.split_pts[i - 1]:self.split_pts[i]] = i - 1
+        self.full_ard_weights = torch.from_numpy(full).to(self.device)
+        self.ard_position_key = torch.from_numpy(key).to(self.device)
+
+    def set_hyperparams(self, hyperparams, logspace=True):
+        super().set_hyperparams(hyperparams, logspace)
+        self._set_ard_arrays()
+
+    supports_fused = False
+
+    def fused_ok(self):
+        return False
+
+    def _typed(self, t):
+        return t.to(torch.float64 if self.double_precision else torch.float32).contiguous()
+
+    def transform_x(self, input_x, sequence_length=None):
+        """kernel_baseclass.py:269-299 with mini_ard.py:171-194 (no sigma pre-multiplication: the
+        per-feature weights carry the lengthscales)."""
+        xin = self._typed(self._as_device_f32(input_x))             # the private typed copy (:274-288)
+        xtrans = self._typed(xin.to(torch.float64) * self.full_ard_weights[None, :])
+        output_x = torch.zeros((xtrans.shape[0], self.num_rffs), dtype=torch.float64, device=self.device)
+        ext.hipRBFFeatureGen(xtrans, output_x, self.radem_diag, self._typed(self.chi_arr), self.fit_intercept)
+        if self.fit_intercept:
+            output_x[:, 0] = 1.
+        return output_x
+
+    def precompute_weights(self):
+        """mini_ard.py:196-238, on the device in float64."""
+        p = self.padded_dims
+        norm_constant = 1.0 / (2.0 ** (np.log2(p) / 2.0))
+        padded_chi = torch.zeros(self.nblocks * p, dtype=torch.float64, device=self.device)
+        padded_chi[:self.chi_arr.shape[0]] = self.chi_arr.to(torch.float64)
+        radem = self.radem_diag.to(torch.float64)
+        blocks = []
+        for i in range(self.nblocks):
+            ident = torch.eye(p, dtype=torch.float64, device=self.device)
+            lo, hi = i * p, (i + 1) * p
+            for r in range(3):
+                ident *= radem[r:r + 1, 0, lo:hi] * norm_constant
+                ext.hipFastHadamardTransform2D(ident)
+            ident *= padded_chi[lo:hi]
+            blocks.append(ident.T[:, :self._xdim[-1]])
+        self.precomputed_weights = self._typed(torch.cat(blocks)[:self.num_freqs, :])
+
+    def kernel_specific_gradient(self, input_x, sequence_length=None):
+        """mini_ard.py:240-275."""
+        if self.precomputed_weights is None:
+            self.precompute_weights()
+        nl = self.split_pts.shape[0] - 1
+        xtrans = torch.zeros((input_x.shape[0], self.num_rffs), dtype=torch.float64, device=self.device)
+        dz_dsigma = torch.zeros((input_x.shape[0], self.num_rffs, nl), dtype=torch.float64, device=self.device)
+        ext.hipMiniARDGrad(input_x, xtrans, self.precomputed_weights, self.ard_position_key,
+                           self.full_ard_weights, dz_dsigma, self.fit_intercept)
+        return xtrans, dz_dsigma
+
+    def gradient_x(self, input_x, sequence_length=None):
+        xin = self._typed(self._as_device_f32(input_x))
+        xtrans, xgrad = self.kernel_specific_gradient(xin, sequence_length)
+        if self.fit_intercept:
+            xtrans[:, 0] = 1.
+            xgrad[:, 0, :] = 0.
+        return xtrans, xgrad
+
+
 _FIXED = ("RBF", "Matern", "Cauchy")
 _CONV = ("Conv1dRBF", "Conv1dMatern", "Conv1dCauchy", "GraphRBF", "GraphMatern", "GraphCauchy")
 
@@ -337,8 +455,10 @@ def make_kernel(kernel_choice, xdim, num_rffs, random_seed=123, device="cuda", k
         return SORFKernel(kernel_choice, xdim, num_rffs, random_seed, device, kernel_spec_parms)
     if kernel_choice in _CONV:
         return ConvSORFKernel(kernel_choice, xdim, num_rffs, random_seed, device, kernel_spec_parms)
+    if kernel_choice == "MiniARD":
+        return MiniARDKernel(xdim, num_rffs, random_seed, device, False, kernel_spec_parms)
     raise RuntimeError(f"kernel '{kernel_choice}' is outside the hot path this package implements "
-                       f"(supported: {_FIXED + _CONV})")
+                       f"(supported: {_FIXED + _CONV + ('MiniARD',)})")
 
 
 class SRHTCompressor:

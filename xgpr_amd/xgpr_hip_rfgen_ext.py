@@ -137,6 +137,22 @@ def hipRBFGrad(inputArr, outputArr, gradArr, radem, chiArr, sigma, fitIntercept)
         int(bool(fitIntercept)), wp, wn, _stream()))
 
 
+def hipMiniARDGrad(inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gradArr, fitIntercept):
+    """cudaMiniARDGrad (xgpr_cuda_rfgen_cpp_ext.cpp:50-60)."""
+    s = _ftype(inputArr, "inputArr")
+    x = _dev(inputArr, "inputArr", None, 2)
+    o = _dev(outputArr, "outputArr", torch.float64, 2)
+    w = _dev(precompWeights, "precompWeights", inputArr.dtype, 2)
+    mp = _dev(sigmaMap, "sigmaMap", torch.int32, 1)
+    sv = _dev(sigmaVals, "sigmaVals", torch.float64, 1)
+    g = _dev(gradArr, "gradArr", torch.float64, 3)
+    fn = getattr(_LIB, f"xgpr_mini_ard_grad_{s}")
+    return _lib.check(fn(x, o, w, mp, sv, g, inputArr.shape[0], inputArr.shape[1], outputArr.shape[0],
+                         outputArr.shape[1], precompWeights.shape[0], precompWeights.shape[1], sigmaMap.shape[0],
+                         sigmaVals.shape[0], gradArr.shape[0], gradArr.shape[1], gradArr.shape[2],
+                         int(bool(fitIntercept)), _stream()))
+
+
 def hipConv1dFGen(inputArr, outputArr, radem, chiArr, seqlengths, convWidth, scalingType):
     """cudaConv1dFGen (xgpr_cuda_rfgen_cpp_ext.cpp:70-80); results are added into outputArr."""
     s = _ftype(inputArr, "inputArr")
@@ -362,6 +378,7 @@ cudaFastHadamardTransform2D = hipFastHadamardTransform2D
 cudaSRHT = hipSRHT
 cudaRBFFeatureGen = hipRBFFeatureGen
 cudaRBFGrad = hipRBFGrad
+cudaMiniARDGrad = hipMiniARDGrad
 cudaConv1dMaxpool = hipConv1dMaxpool
 cudaConv1dFGen = hipConv1dFGen
 cudaConvGrad = hipConvGrad
