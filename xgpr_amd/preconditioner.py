@@ -66,16 +66,68 @@ def _first_pass(dataset, rank, kernel, random_state, verbose, is_regression=True
     return acc_results, z_trans_y, float(y_trans_y.item()), compressor
 
 
-def initialize_srht(dataset, rank, kernel, random_state, verbose=False, is_regression=True):
-    acc_results, z_trans_y, y_trans_y, compressor = _first_pass(dataset, rank, kernel, random_state, verbose,
-                                                                is_regression)
-    c_mat = compressor.transform_x(acc_results)
+# ---- the small factorizations.  rocSOLVER's SVD / QR of an [M x rank] matrix are Jacobi / unblocked
+# Householder sweeps (0.08 s at rank 512, 2.5 s at rank 2048 -- longer than the accumulation passes they
+# follow), while GEMM, Cholesky, triangular solves and the symmetric eigensolver of a rank x rank matrix are
+# fast.  Each helper takes the GEMM-rich route when the matrix is safely conditioned for it and otherwise
+# falls back to the factorization the reference calls, so degenerate problems (fewer datapoints than rank)
+# behave exactly as before.  The routes differ from the reference's LAPACK calls only in column signs / basis
+# of intermediate factors, which cancel in U diag(eig) U^T.
+GRAM_COND_LIMIT = 1e7        # eigenvalue ratio up to which the Gram-matrix route keeps ~1e-9 relative accuracy
+
+
+def _inv_sqrt_apply(acc_t, c_mat):
+    """acc_t @ C^(-1/2) for the symmetric positive semi-definite sketch C (rand_nys_constructors.py:275-285,
+    where the reference takes an SVD of C)."""
+    c_sym = 0.5 * (c_mat + c_mat.T)
+    if float((c_mat - c_mat.T).abs().max().item()) <= 1e-9 * float(c_mat.abs().max().item()):
+        evals, evecs = torch.linalg.eigh(c_sym)
+        if float(evals[0].item()) * GRAM_COND_LIMIT > float(evals[-1].item()) > 0:
+            return ((acc_t @ evecs) * torch.rsqrt(evals)[None, :]) @ evecs.T
     _, c_s1, c_v1 = torch.linalg.svd(c_mat, full_matrices=False)
     mask = c_s1 < 1e-14
     c_s1 = 1 / torch.sqrt(c_s1.clip(min=1e-14))
     c_s1[mask] = 0
-    acc_results = acc_results.T @ c_v1.T @ (c_s1[:, None] * c_v1)
-    u_mat, s_mat, _ = torch.linalg.svd(acc_results, full_matrices=False)
+    return acc_t @ c_v1.T @ (c_s1[:, None] * c_v1)
+
+
+def _tall_svd(b_mat):
+    """(U, s) of the thin SVD of b_mat [M, rank] (rand_nys_constructors.py:212, :290)."""
+    gram = b_mat.T @ b_mat
+    evals, evecs = torch.linalg.eigh(gram)
+    if float(evals[0].item()) * GRAM_COND_LIMIT > float(evals[-1].item()) > 0:
+        s_mat = torch.sqrt(evals.flip(0))
+        u_mat = (b_mat @ evecs.flip(1)) / s_mat[None, :]
+        return u_mat, s_mat
+    u_mat, s_mat, _ = torch.linalg.svd(b_mat, full_matrices=False)
+    return u_mat, s_mat
+
+
+def _orthonormal_basis(a_mat):
+    """Q of the thin QR of a_mat [M, rank] up to column signs (rand_nys_constructors.py:187): two rounds of
+    Cholesky QR, checked, with Householder QR as the fallback."""
+    q_mat = a_mat
+    ok = True
+    for _ in range(2):
+        chol, info = torch.linalg.cholesky_ex(q_mat.T @ q_mat)
+        if int(info.item()) != 0:
+            ok = False
+            break
+        q_mat = torch.linalg.solve_triangular(chol, q_mat.T, upper=False).T
+    if ok:
+        eye_err = q_mat.T @ q_mat
+        eye_err.diagonal().sub_(1.0)
+        if float(eye_err.abs().max().item()) < 1e-11:
+            return q_mat.contiguous()
+    return torch.linalg.qr(a_mat)[0]
+
+
+def initialize_srht(dataset, rank, kernel, random_state, verbose=False, is_regression=True):
+    acc_results, z_trans_y, y_trans_y, compressor = _first_pass(dataset, rank, kernel, random_state, verbose,
+                                                                is_regression)
+    c_mat = compressor.transform_x(acc_results)
+    acc_results = _inv_sqrt_apply(acc_results.T, c_mat)
+    u_mat, s_mat = _tall_svd(acc_results)
     s_mat = s_mat ** 2
     return u_mat, s_mat, z_trans_y, y_trans_y
 
@@ -86,7 +138,7 @@ def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False
     acc_results = acc_results.T.contiguous()
     q_mat = None
     for _ in range(n_passes - 1):
-        q_mat, _r = torch.linalg.qr(acc_results)
+        q_mat = _orthonormal_basis(acc_results)
         acc_results.zero_()
         single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose)
         comm.all_reduce_(acc_results)
@@ -96,7 +148,7 @@ def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False
     q_mat = q_mat.T @ acc_results
     q_mat = torch.linalg.cholesky(q_mat)
     acc_results = torch.linalg.solve_triangular(q_mat, acc_results.T, upper=False).T
-    u_mat, s_mat, _ = torch.linalg.svd(acc_results, full_matrices=False)
+    u_mat, s_mat = _tall_svd(acc_results)
     s_mat = (s_mat ** 2 - shift).clip(min=0)
     return u_mat, s_mat, z_trans_y, y_trans_y
 
