@@ -205,6 +205,21 @@ int xgpr_zcache_matvec_f32(const float *zc, const double *v, double *w_out, long
 int xgpr_zcache_matvec_scaled_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs,
                                   double scale, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- SRHTCompressor.transform_x in one pass (srht_compressor.py:87-97: zero-pad the chunk to the padded
+ * width, cudaSRHT in place, gather the sampled columns): out[i, c] = SRHT(z_i)[sampler[c]] for c < ncols,
+ * z [n, m] and out [n, ldo] of the same type, radem int8 [padded_width], sampler int64 [>= ncols], all on the
+ * device.  z is not modified.  With y != NULL (float64 [n]) the same read of z also produces the chunk's
+ * z^T y (`z_trans_y += xdata.T @ ydata`, rand_nys_constructors.py:115) in zty_out [m] (overwritten;
+ * deterministic), using xgpr_srht_sample_workspace_bytes(m) of workspace.  The padded row must fit in LDS
+ * (float64: padded_width <= 16384). */
+size_t xgpr_srht_sample_workspace_bytes(long m);
+int xgpr_srht_sample_f32(const float *z, const int8_t *radem, const long *sampler, float *out, const double *y,
+                         double *zty_out, long n, long m, long padded_width, long ncols, long ldo,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_srht_sample_f64(const double *z, const int8_t *radem, const long *sampler, double *out, const double *y,
+                         double *zty_out, long n, long m, long padded_width, long ncols, long ldo,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- cudaMiniARDGrad(inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gradArr, fitIntercept)
  * (gpu_rf_gen/xgpr_cuda_rfgen_cpp_ext.cpp:50-60; cpu_rf_gen/rbf_ops/ard_ops.cpp:39-124): MiniARD random
  * features out[n, num_rffs] and their gradient grad[n, num_rffs, num_lengthscales] w.r.t. the per-group

@@ -123,8 +123,12 @@ class OracleBackedCompressor:
         from oracle import oracle as orc
         self.inner = orc.OracleSRHTCompressor(compression_size, input_size, random_seed)
 
-    def transform_x(self, features, no_compression=False):
-        return torch.from_numpy(self.inner.transform_x(features.numpy(), no_compression))
+    def transform_x(self, features, no_compression=False, out=None):
+        res = torch.from_numpy(self.inner.transform_x(features.numpy(), no_compression))
+        if out is None:
+            return res
+        out[:, :res.shape[1]] = res
+        return out[:, :res.shape[1]]
 
 
 def _class_problem():

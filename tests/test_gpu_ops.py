@@ -390,3 +390,37 @@ def test_g12_mini_ard_grad_and_kernel_vs_reference_ground_truth(oracle):
     with pytest.raises(RuntimeError):
         ext.hipMiniARDGrad(xt, torch.zeros((4, 16), dtype=torch.float64, device=DEV), w, mp[:5], sv,
                            torch.zeros((4, 16, 1), dtype=torch.float64, device=DEV), True)
+
+
+@pytest.mark.parametrize("n,m,rank", [(37, 8192, 512), (5, 300, 17), (3, 4, 2), (64, 16384, 2048), (9, 4097, 100)])
+def test_srht_sample_equals_pad_srht_gather(oracle, n, m, rank):
+    """hipSRHTSample == SRHTCompressor's reference formulation (srht_compressor.py:87-97: zero-pad, cudaSRHT
+    in place, gather) bit for bit, and == the oracle's compressor; the input is left untouched."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import SRHTCompressor
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(n + m)
+    z = rng.standard_normal((n, m))
+    comp = SRHTCompressor(rank, m, device=DEV, random_seed=123)
+    zd = torch.from_numpy(z).to(DEV)
+    zcopy = zd.clone()
+    fused = comp.transform_x(zd)
+    assert torch.equal(zd, zcopy)
+    # the reference formulation with the separate operators
+    xf = torch.zeros((n, comp.padded_dims), dtype=torch.float64, device=DEV)
+    xf[:, :m] = zd
+    ext.hipSRHT(xf, comp.radem)
+    assert torch.equal(fused, xf[:, comp.truncated_sampler])
+    ocomp = orc.OracleSRHTCompressor(rank, m, random_seed=123, ops=oracle)
+    assert np.array_equal(fused.cpu().numpy(), ocomp.transform_x(z))
+    # the same pass can also deliver z^T y (the preconditioner's first pass)
+    y = rng.standard_normal(n)
+    zty = torch.full((m,), 3.0, dtype=torch.float64, device=DEV)
+    both = comp.transform_x_zty(zd, torch.from_numpy(y).to(DEV), zty)
+    assert torch.equal(both, fused) and torch.equal(zd, zcopy)
+    ref = z.T @ y
+    assert np.linalg.norm(zty.cpu().numpy() - ref) <= 1e-13 * max(np.linalg.norm(ref), 1e-300)
+    # into a wider preallocated buffer (row pitch rank + 1)
+    buf = torch.full((n, rank + 1), -7.0, dtype=torch.float64, device=DEV)
+    view = comp.transform_x(zd, out=buf)
+    assert torch.equal(view, fused) and bool((buf[:, rank] == -7.0).all())

@@ -19,6 +19,8 @@ SIGNATURES = {
     "xgpr_fht_f64": [_vp, _l, _l, _l, _vp],
     "xgpr_srht_f32": [_vp, _vp, _l, _l, _l, _vp],
     "xgpr_srht_f64": [_vp, _vp, _l, _l, _l, _vp],
+    "xgpr_srht_sample_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _vp, _sz, _vp],
+    "xgpr_srht_sample_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _vp, _sz, _vp],
     "xgpr_rbf_feature_gen_f32": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_rbf_feature_gen_f64": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_rbf_grad_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _d, _i, _vp, _sz, _vp],
@@ -52,6 +54,7 @@ SIZE_FUNCS = {
     "xgpr_precond_apply_workspace_bytes": [_l],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
     "xgpr_zcache_block_workspace_bytes": [_l, _l, _l],
+    "xgpr_srht_sample_workspace_bytes": [_l],
 }
 STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch"]
 

@@ -195,6 +195,53 @@ __global__ void generic_fht_kernel(T *x, const int8_t *__restrict__ radem, long 
     }
 }
 
+// SRHT of each row of z[n, m] (zero padded to P) followed by the column sample, out of place:
+// out[i, c] = FHT(z_i * radem * nc)[sampler[c]], c < ncols (srht_compressor.py:87-97, where the
+// reference pads, transforms the whole chunk in place and then gathers).  A workgroup walks rows
+// blockIdx.x, blockIdx.x + gridDim.x, ...; each row is read once and only ncols of the P transformed
+// values are written.  With y != nullptr the same read also accumulates the chunk's z^T y
+// (rand_nys_constructors.py:115) -- thread t keeps the columns t, t + nt, ... in registers and the
+// workgroup's partial sums go to zty_part[blockIdx.x, m] for an ordered reduction.
+constexpr int SRHT_ZTY_COLS = 16;      // columns per thread: P <= 16 * blockDim
+
+template <typename T>
+__global__ void srht_sample_kernel(const T *__restrict__ z, const int8_t *__restrict__ radem,
+                                   const long *__restrict__ sampler, T *out, const double *__restrict__ y,
+                                   double *zty_part, long n, long m, int P, long ncols, long ldo, T nc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *buf = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double acc[SRHT_ZTY_COLS];
+    #pragma unroll
+    for (int q = 0; q < SRHT_ZTY_COLS; q++) acc[q] = 0.0;
+    for (long row = blockIdx.x; row < n; row += gridDim.x) {
+        const T *zr = z + row * m;
+        const double yi = y ? y[row] : 0.0;
+        #pragma unroll
+        for (int q = 0; q < SRHT_ZTY_COLS; q++) {
+            const int e = tid + q * nt;
+            if (e < P) {
+                const T v = e < m ? zr[e] : (T)0;
+                acc[q] = __builtin_fma(yi, (double)v, acc[q]);
+                buf[e] = v * (radem[e] * nc);
+            }
+        }
+        __syncthreads();
+        lds_fht<T>(buf, P, P, tid, nt);
+        T *orow = out + row * ldo;
+        for (long c = tid; c < ncols; c += nt) orow[c] = buf[sampler[c]];
+        __syncthreads();                 // buf is rewritten for the next row
+    }
+    if (y) {
+        double *slab = zty_part + (long)blockIdx.x * m;
+        #pragma unroll
+        for (int q = 0; q < SRHT_ZTY_COLS; q++) {
+            const int e = tid + q * nt;
+            if (e < m) slab[e] = acc[q];
+        }
+    }
+}
+
 // one butterfly stage of stride h straight in global memory (only for P > LDS capacity)
 template <typename T>
 __global__ void global_stage_kernel(T *x, long npairs, long h) {
@@ -2193,6 +2240,42 @@ int mini_ard_impl(const T *x, double *out, const T *weights, const int32_t *sigm
     return 0;
 }
 
+constexpr long SRHT_ZTY_MAX_BLOCKS = 512;
+
+template <typename T>
+int srht_sample_impl(const T *z, const int8_t *radem, const long *sampler, T *out, const double *y, double *zty_out,
+                     long n, long m, long P, long ncols, long ldo, void *workspace, size_t wbytes, void *stream) {
+    if (n <= 0 || m <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (P < 2 || (P & (P - 1)) != 0 || m > P) return fail(XGPR_ERR_NOT_POW2, "last dim not power of 2 > 1");
+    if (ncols < 1 || ncols > P || ldo < ncols) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (P > lds_cap_elems<T>()) return fail(XGPR_ERR_UNSUPPORTED, "fused SRHT + sample needs the padded row to fit in LDS");
+    const int nt = threads_for(P);
+    if (P > (long)SRHT_ZTY_COLS * nt) return fail(XGPR_ERR_UNSUPPORTED, "fused SRHT + sample: padded width too large");
+    long nblocks = 2L * device_cus();
+    if (nblocks > n) nblocks = n;
+    if (nblocks > SRHT_ZTY_MAX_BLOCKS) nblocks = SRHT_ZTY_MAX_BLOCKS;
+    double *part = nullptr;
+    if (y) {
+        if (!zty_out) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+        if (!workspace || wbytes < (size_t)nblocks * m * sizeof(double) || !aligned16(workspace))
+            return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_srht_sample_workspace_bytes)");
+        part = reinterpret_cast<double *>(workspace);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)P * sizeof(T);
+    auto kern = srht_sample_kernel<T>;
+    int rc = allow_big_lds(kern, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(nt), lds, st, z, radem, sampler, out, y, part, n, m, (int)P, ncols,
+                       ldo, norm_constant<T>(P));
+    HIP_TRY(hipGetLastError(), "srht_sample_kernel launch");
+    if (y) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, st, part, zty_out, m, nblocks);
+        HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    }
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -2400,6 +2483,20 @@ int xgpr_zcache_block_backproject_f32(const float *zc, const double *r, double *
                                       size_t workspace_bytes, void *stream) {
     return zcache_block_impl(ZB_BACKPROJECT, zc, r, g_out, n, num_rffs, k, fit_intercept, scale, accumulate, workspace,
                              workspace_bytes, stream);
+}
+
+size_t xgpr_srht_sample_workspace_bytes(long m) { return (size_t)SRHT_ZTY_MAX_BLOCKS * (m > 0 ? m : 0) * sizeof(double); }
+int xgpr_srht_sample_f64(const double *z, const int8_t *radem, const long *sampler, double *out, const double *y,
+                         double *zty_out, long n, long m, long padded_width_, long ncols, long ldo, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+    return srht_sample_impl<double>(z, radem, sampler, out, y, zty_out, n, m, padded_width_, ncols, ldo, workspace,
+                                    workspace_bytes, stream);
+}
+int xgpr_srht_sample_f32(const float *z, const int8_t *radem, const long *sampler, float *out, const double *y,
+                         double *zty_out, long n, long m, long padded_width_, long ncols, long ldo, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+    return srht_sample_impl<float>(z, radem, sampler, out, y, zty_out, n, m, padded_width_, ncols, ldo, workspace,
+                                   workspace_bytes, stream);
 }
 
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {

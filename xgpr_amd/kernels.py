@@ -476,11 +476,40 @@ class SRHTCompressor:
         self.device = device
         self.radem = torch.from_numpy(radem).to(device)
         self.col_sampler = torch.from_numpy(col_sampler).to(device)
-        self.truncated_sampler = self.col_sampler[:compression_size]
+        self.truncated_sampler = self.col_sampler[:compression_size].contiguous()
+        self._zty_ws = None
 
-    def transform_x(self, features, no_compression=False):
+    def fused_ok(self, features):
+        return (features.is_cuda and features.dtype == torch.float64 and features.is_contiguous()
+                and ext.srht_sample_ok(self.padded_dims, torch.float64))
+
+    def transform_x_zty(self, features, ydata, zty_out, out=None):
+        """The compressed chunk AND ``features.T @ ydata`` (into zty_out) from one read of the chunk
+        (rand_nys_constructors.py:113-117)."""
+        if self.fused_ok(features):
+            if out is None:
+                out = torch.empty((features.shape[0], self.compression_size), dtype=torch.float64,
+                                  device=features.device)
+            if self._zty_ws is None:
+                self._zty_ws = torch.empty(ext.srht_sample_workspace_bytes(self.input_size), dtype=torch.uint8,
+                                           device=features.device)
+            ext.hipSRHTSample(features, self.radem, self.truncated_sampler, out, self.compression_size,
+                              ydata, zty_out, self._zty_ws)
+            return out[:, :self.compression_size]
+        torch.matmul(features.T, ydata, out=zty_out)
+        return self.transform_x(features, out=out)
+
+    def transform_x(self, features, no_compression=False, out=None):
+        """srht_compressor.py:87-97.  ``out``: optional preallocated float64 [n, >= compression_size] array
+        whose leading columns receive the result (the fused pad + SRHT + gather operator writes into it)."""
         if features.dim() != 2 or features.shape[1] != self.input_size:
             raise RuntimeError("Input with unexpected size passed to a compressor module.")
+        if not no_compression and self.fused_ok(features):
+            if out is None:
+                out = torch.empty((features.shape[0], self.compression_size), dtype=torch.float64,
+                                  device=features.device)
+            ext.hipSRHTSample(features, self.radem, self.truncated_sampler, out, self.compression_size)
+            return out[:, :self.compression_size]
         if features.shape[1] < self.padded_dims:
             xfeatures = torch.zeros((features.shape[0], self.padded_dims), dtype=torch.float64,
                                     device=self.device)
@@ -490,4 +519,7 @@ class SRHTCompressor:
         ext.hipSRHT(xfeatures, self.radem)
         if no_compression:
             return xfeatures[:, self.col_sampler]
+        if out is not None:
+            out[:, :self.compression_size] = xfeatures[:, self.truncated_sampler]
+            return out[:, :self.compression_size]
         return xfeatures[:, self.truncated_sampler]

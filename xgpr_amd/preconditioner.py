@@ -21,12 +21,21 @@ from .kernels import SRHTCompressor
 
 
 def single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose):
+    """rand_nys_constructors.py:96-123.  The compressed chunk and the chunk's z^T y come out of one read of
+    Z (hipSRHTSample) instead of a copy + in-place SRHT + gather and a separate library GEMV; the
+    accumulation itself is the float64 MFMA library GEMM."""
     y_trans_y = torch.zeros(1, dtype=torch.float64, device=acc_results.device)
+    zty_chunk = torch.empty_like(z_trans_y)
     for j, (xin, yin, ldata) in enumerate(dataset.get_chunked_data()):
         xdata, ydata = kernel.transform_x_y(xin, yin, ldata)
-        z_trans_y += xdata.T @ ydata
+        if hasattr(compressor, "transform_x_zty"):
+            compressed = compressor.transform_x_zty(xdata, ydata, zty_chunk)
+            z_trans_y += zty_chunk
+        else:
+            z_trans_y += xdata.T @ ydata
+            compressed = compressor.transform_x(xdata)
         y_trans_y += ydata @ ydata
-        acc_results += compressor.transform_x(xdata).T @ xdata
+        acc_results.addmm_(compressed.T, xdata)
         if j % 10 == 0 and verbose:
             print(f"Chunk {j} complete.")
     return y_trans_y
@@ -52,12 +61,13 @@ def single_pass_srht(dataset, kernel, compressor, acc_results, verbose):
 def _first_pass(dataset, rank, kernel, random_state, verbose, is_regression=True):
     comm = dataset.comm
     m = kernel.get_num_rffs()
-    acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
     compressor = SRHTCompressor(rank, m, device=kernel.device, random_seed=random_state)
     if not is_regression:
+        acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
         single_pass_srht(dataset, kernel, compressor, acc_results, verbose)
         comm.all_reduce_(acc_results)
         return acc_results, None, 0, compressor
+    acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
     z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
     y_trans_y = single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose)
     comm.all_reduce_(acc_results)

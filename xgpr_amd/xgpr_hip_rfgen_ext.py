@@ -106,6 +106,43 @@ def _radem3(radem):
     return r
 
 
+def hipSRHTSample(inputArr, radem, sampler, outputArr, ncols=None, yArr=None, ztyOut=None, workspace=None):
+    """``outputArr[:, :ncols] = cudaSRHT(pad(inputArr))[:, sampler[:ncols]]`` without touching inputArr
+    (srht_compressor.py:87-97 in one pass).  outputArr may have more than ncols columns (row pitch).
+    With ``yArr`` the same pass also writes ``inputArr.T @ yArr`` into ``ztyOut``."""
+    s = _ftype(inputArr, "inputArr")
+    x = _dev(inputArr, "inputArr", None, 2)
+    r = _dev(radem, "radem", torch.int8, 1)
+    sm = _dev(sampler, "sampler", torch.int64, 1)
+    o = _dev(outputArr, "outputArr", inputArr.dtype, 2)
+    ncols = sampler.shape[0] if ncols is None else int(ncols)
+    if outputArr.shape[0] != inputArr.shape[0] or outputArr.shape[1] < ncols or sampler.shape[0] < ncols:
+        raise RuntimeError("incorrect array dims passed")
+    yp = zp = wp = C.c_void_p(0)
+    wn = C.c_size_t(0)
+    if yArr is not None:
+        yp = _dev(yArr, "yArr", torch.float64, 1)
+        zp = _dev(ztyOut, "ztyOut", torch.float64, 1)
+        if yArr.shape[0] != inputArr.shape[0] or ztyOut.shape[0] != inputArr.shape[1]:
+            raise RuntimeError("incorrect array dims passed")
+        if workspace is None:
+            workspace = torch.empty(int(_LIB.xgpr_srht_sample_workspace_bytes(inputArr.shape[1])), dtype=torch.uint8,
+                                    device=inputArr.device)
+        wp, wn = C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel())
+    fn = getattr(_LIB, f"xgpr_srht_sample_{s}")
+    return _lib.check(fn(x, r, sm, o, yp, zp, inputArr.shape[0], inputArr.shape[1], radem.shape[0], ncols,
+                         outputArr.shape[1], wp, wn, _stream()))
+
+
+def srht_sample_workspace_bytes(m):
+    return int(_LIB.xgpr_srht_sample_workspace_bytes(m))
+
+
+def srht_sample_ok(padded_width, dtype):
+    """Whether hipSRHTSample covers this padded width (the row must fit in LDS)."""
+    return padded_width * (8 if dtype == torch.float64 else 4) <= 128 * 1024
+
+
 def hipRBFFeatureGen(inputArr, outputArr, radem, chiArr, fitIntercept):
     """cudaRBFFeatureGen (xgpr_cuda_rfgen_cpp_ext.cpp:32-40).  The output is overwritten
     (as by the reference's CUDA kernel, rbf_ops.cu:121-127)."""
