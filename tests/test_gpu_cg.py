@@ -246,3 +246,41 @@ def test_conv_cg_with_feature_cache_matches_oracle(oracle):
     wref, nref, _, _ = orc.cg_fit_lib_internal(okern, ods, 1e-9, 300, None)
     assert abs(niter - nref) <= 1
     assert rel(w, wref) < 1e-5
+
+
+@pytest.mark.parametrize("method", ["srht", "srht_2"])
+def test_conv_preconditioned_cg_sharing_one_feature_pass_matches_oracle(oracle, method):
+    """Convolution kernel: the preconditioner passes take their feature chunks from the resident float32
+    cache (cache_features="auto" for kernels that cannot regenerate cheaply) and the CG solve streams the same
+    cache -- one generation pass in total -- against the oracle's preconditioned CG on float64 features."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import cg_fit_lib_internal
+    rng = np.random.default_rng(77)
+    n, L, C, m = 500, 20, 6, 256
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(6, L + 1, size=n).astype(np.int32)
+    y = rng.standard_normal(n)
+    hp = np.array([0.4, 0.6])
+    ds = build_regression_dataset(x, y, sl, chunk_size=128, device=DEV)
+    kern = make_kernel("Conv1dRBF", x.shape, m, 123, DEV, {"conv_width": 5, "averaging": "sqrt"})
+    kern.set_hyperparams(hp, logspace=False)
+    calls = {"n": 0}
+    orig = kern.transform_x
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    kern.transform_x = counting
+    pre = RandNysPreconditioner(kern, ds, 32, False, 123, method)
+    w, niter, _ = cg_fit_lib_internal(kern, ds, 1e-9, 300, pre, False, cache_features=True)
+    assert calls["n"] == 4                          # ceil(500 / 128) chunks, generated exactly once
+    ods = orc.OracleDataset(x.astype(np.float64), y, sl, chunk_size=128)
+    okern = orc.OracleKernel("Conv1dRBF", m, x.shape, hp, 123, conv_width=5, averaging="sqrt", ops=oracle)
+    opre = orc.OracleRandNysPreconditioner(okern, ods, 32, 123, method)
+    assert np.isclose(pre.achieved_ratio, opre.achieved_ratio, rtol=1e-5)
+    wref, nref, _, _ = orc.cg_fit_lib_internal(okern, ods, 1e-9, 300, opre)
+    assert abs(niter - nref) <= 1
+    assert rel(w, wref) < 1e-5

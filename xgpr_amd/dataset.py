@@ -89,6 +89,21 @@ class DeviceDataset:
             self._zcache_key = key
         return self._zcache
 
+    def get_chunked_features(self, kernel, with_y=False, from_cache=False):
+        """Chunks of the float64 feature matrix (``kernel.transform_x`` of each x chunk), optionally with the
+        standardised y chunk.  ``from_cache``: widen rows of the resident float32 feature cache instead of
+        regenerating them -- for the convolution kernels, whose features cost K k-mers x SORF per sequence,
+        this lets the preconditioner passes and the CG solve share one generation pass."""
+        zc = self.feature_cache(kernel) if from_cache else None
+        row = 0
+        for xin, yin, ldata in self.get_chunked_data():
+            if zc is None:
+                z = kernel.transform_x(xin, ldata)
+            else:
+                z = kernel.cache_rows_to_features(zc[row:row + xin.shape[0]])
+            row += xin.shape[0]
+            yield (z, yin) if with_y else z
+
     def feature_cache_bytes(self, kernel):
         return self._xdata.shape[0] * kernel.get_num_rffs() * 4
 

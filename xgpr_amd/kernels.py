@@ -178,6 +178,16 @@ class SORFKernel(KernelBase):
     def ztz_block_cached(self, zcache, vecs, out, workspace, accumulate=False):
         _block_matvec(zcache, vecs, out, workspace, self.fit_intercept, 0.0, accumulate)
 
+    def cache_rows_to_features(self, zrows):
+        """float64 feature rows (what transform_x returns) from rows of the float32 cache: the cache holds
+        the (cos, sin) values before scaling, the operator widens them and multiplies by its float-typed
+        constant (rbf_ops.cpp:68-72)."""
+        scale = float(np.float32(np.sqrt(1.0 / (self.num_freqs - 0.5 if self.fit_intercept else self.num_freqs))))
+        z = zrows.to(torch.float64) * scale
+        if self.fit_intercept:
+            z[:, 0] = 1.
+        return z
+
     def fused_ok(self):
         """The fused kernels cover padded width <= 1024 (single pass up to num_freqs = 8192, the
         two-pass form beyond, up to 65536)."""
@@ -292,6 +302,10 @@ class ConvSORFKernel(KernelBase):
 
     def ztz_block_cached(self, zcache, vecs, out, workspace, accumulate=False):
         _block_matvec(zcache, vecs, out, workspace, False, 1.0, accumulate)
+
+    def cache_rows_to_features(self, zrows):
+        """the convolution cache holds complete feature rows rounded to float32"""
+        return zrows.to(torch.float64)
 
     def workspace_bytes(self):
         return ext.ztz_workspace_bytes(self.num_rffs, self.radem_diag.shape[2])

@@ -20,14 +20,22 @@ import torch
 from .kernels import SRHTCompressor
 
 
-def single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose):
+def _feature_chunks(dataset, kernel, with_y, from_cache):
+    if hasattr(dataset, "get_chunked_features"):
+        return dataset.get_chunked_features(kernel, with_y, from_cache)
+    if with_y:
+        return (kernel.transform_x_y(xin, yin, ldata) for xin, yin, ldata in dataset.get_chunked_data())
+    return (kernel.transform_x(xin, ldata) for xin, ldata in dataset.get_chunked_x_data())
+
+
+def single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose, from_cache=False):
     """rand_nys_constructors.py:96-123.  The compressed chunk and the chunk's z^T y come out of one read of
     Z (hipSRHTSample) instead of a copy + in-place SRHT + gather and a separate library GEMV; the
     accumulation itself is the float64 MFMA library GEMM."""
     y_trans_y = torch.zeros(1, dtype=torch.float64, device=acc_results.device)
     zty_chunk = torch.empty_like(z_trans_y)
-    for j, (xin, yin, ldata) in enumerate(dataset.get_chunked_data()):
-        xdata, ydata = kernel.transform_x_y(xin, yin, ldata)
+    for j, (xdata, ydata) in enumerate(_feature_chunks(dataset, kernel, True, from_cache)):
+        ydata = ydata.to(torch.float64)
         if hasattr(compressor, "transform_x_zty"):
             compressed = compressor.transform_x_zty(xdata, ydata, zty_chunk)
             z_trans_y += zty_chunk
@@ -41,35 +49,33 @@ def single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, ve
     return y_trans_y
 
 
-def single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose):
-    for j, (xdata, ldata) in enumerate(dataset.get_chunked_x_data()):
-        xdata = kernel.transform_x(xdata, ldata)
+def single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose, from_cache=False):
+    for j, xdata in enumerate(_feature_chunks(dataset, kernel, False, from_cache)):
         acc_results += xdata.T @ (xdata @ q_mat)
         if j % 10 == 0 and verbose:
             print(f"Chunk {j} complete.")
 
 
-def single_pass_srht(dataset, kernel, compressor, acc_results, verbose):
+def single_pass_srht(dataset, kernel, compressor, acc_results, verbose, from_cache=False):
     """rand_nys_constructors.py:39-56 (classification: no z^T y)."""
-    for j, (xin, ldata) in enumerate(dataset.get_chunked_x_data()):
-        xdata = kernel.transform_x(xin, ldata)
+    for j, xdata in enumerate(_feature_chunks(dataset, kernel, False, from_cache)):
         acc_results += compressor.transform_x(xdata).T @ xdata
         if j % 10 == 0 and verbose:
             print(f"Chunk {j} complete.")
 
 
-def _first_pass(dataset, rank, kernel, random_state, verbose, is_regression=True):
+def _first_pass(dataset, rank, kernel, random_state, verbose, is_regression=True, from_cache=False):
     comm = dataset.comm
     m = kernel.get_num_rffs()
     compressor = SRHTCompressor(rank, m, device=kernel.device, random_seed=random_state)
     if not is_regression:
         acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
-        single_pass_srht(dataset, kernel, compressor, acc_results, verbose)
+        single_pass_srht(dataset, kernel, compressor, acc_results, verbose, from_cache)
         comm.all_reduce_(acc_results)
         return acc_results, None, 0, compressor
     acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
     z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
-    y_trans_y = single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose)
+    y_trans_y = single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose, from_cache)
     comm.all_reduce_(acc_results)
     comm.all_reduce_(z_trans_y)
     comm.all_reduce_(y_trans_y)
@@ -132,9 +138,9 @@ def _orthonormal_basis(a_mat):
     return torch.linalg.qr(a_mat)[0]
 
 
-def initialize_srht(dataset, rank, kernel, random_state, verbose=False, is_regression=True):
+def initialize_srht(dataset, rank, kernel, random_state, verbose=False, is_regression=True, from_cache=False):
     acc_results, z_trans_y, y_trans_y, compressor = _first_pass(dataset, rank, kernel, random_state, verbose,
-                                                                is_regression)
+                                                                is_regression, from_cache)
     c_mat = compressor.transform_x(acc_results)
     acc_results = _inv_sqrt_apply(acc_results.T, c_mat)
     u_mat, s_mat = _tall_svd(acc_results)
@@ -142,15 +148,17 @@ def initialize_srht(dataset, rank, kernel, random_state, verbose=False, is_regre
     return u_mat, s_mat, z_trans_y, y_trans_y
 
 
-def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False, n_passes=1, is_regression=True):
+def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False, n_passes=1, is_regression=True,
+                              from_cache=False):
     comm = dataset.comm
-    acc_results, z_trans_y, y_trans_y, _ = _first_pass(dataset, rank, kernel, random_state, verbose, is_regression)
+    acc_results, z_trans_y, y_trans_y, _ = _first_pass(dataset, rank, kernel, random_state, verbose, is_regression,
+                                                       from_cache)
     acc_results = acc_results.T.contiguous()
     q_mat = None
     for _ in range(n_passes - 1):
         q_mat = _orthonormal_basis(acc_results)
         acc_results.zero_()
-        single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose)
+        single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose, from_cache)
         comm.all_reduce_(acc_results)
     norm = float(torch.sqrt((acc_results ** 2).sum()).item())
     shift = float(np.spacing(norm))
@@ -167,16 +175,27 @@ class RandNysPreconditioner:
     """Preconditioner from the randomized Nystrom approximation of (Z^T Z + lambda^2)^-1."""
 
     def __init__(self, kernel, dataset, max_rank, verbose=False, random_state=123, method="srht",
-                 is_regression=True):
+                 is_regression=True, cache_features="auto"):
+        """``cache_features``: take the feature chunks of the accumulation passes from the dataset's resident
+        float32 feature cache (building it if needed) instead of regenerating them.  "auto": only for kernels
+        whose features are expensive to regenerate (the convolution kernels) and when the cache fits; the
+        solve that follows then reuses the same cache."""
         if method not in ["srht_2", "srht_3", "srht"]:
             raise RuntimeError("Unknown method supplied for tuning preconditioner construction.")
+        if cache_features == "auto":
+            from .cg import _resolve_cache_mode
+            from_cache = (hasattr(kernel, "fused_ok") and not kernel.fused_ok()
+                          and hasattr(kernel, "cache_rows_to_features")
+                          and _resolve_cache_mode("auto", kernel, dataset, block=True))
+        else:
+            from_cache = bool(cache_features)
         if method.startswith("srht_"):
             n_passes = int(method.split("_")[1])
             self.u_mat, self.eig, self.z_trans_y, self.y_trans_y = initialize_srht_multipass(
-                dataset, max_rank, kernel, random_state, verbose, n_passes, is_regression)
+                dataset, max_rank, kernel, random_state, verbose, n_passes, is_regression, from_cache)
         else:
             self.u_mat, self.eig, self.z_trans_y, self.y_trans_y = initialize_srht(
-                dataset, max_rank, kernel, random_state, verbose, is_regression)
+                dataset, max_rank, kernel, random_state, verbose, is_regression, from_cache)
         lambda_ = float(kernel.get_lambda())
         min_eig = float(self.eig.min().item())
         self.eig = self.eig + lambda_ ** 2
