@@ -103,3 +103,26 @@ def test_fused_matvec_small_n_and_odd_tiles(oracle):
         ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), dev(v), w, True)
         ref = z.T @ (z @ v)
         assert np.abs(w.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), (n, d, rffs)
+
+
+def test_offline_dataset_on_device(tmp_path):
+    """.npy chunk files -> pinned host buffers -> HBM shard (loader thread + copy stream); a fit on it equals
+    the fit on the in-memory dataset."""
+    from xgpr_amd.dataset import build_offline_np_dataset, build_regression_dataset
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.cg import cg_fit_lib_internal
+    rng = np.random.default_rng(4)
+    xs, ys, xf, yf = [], [], [], []
+    for i, n in enumerate((300, 211, 256, 40)):
+        x, y = rng.uniform(-1, 1, size=(n, 24)), rng.standard_normal(n)
+        np.save(tmp_path / f"x{i}.npy", x)
+        np.save(tmp_path / f"y{i}.npy", y)
+        xs.append(x), ys.append(y), xf.append(str(tmp_path / f"x{i}.npy")), yf.append(str(tmp_path / f"y{i}.npy"))
+    off = build_offline_np_dataset(xf, yf, chunk_size=300, device="cuda")
+    ref = build_regression_dataset(np.vstack(xs), np.concatenate(ys), chunk_size=300, device="cuda")
+    assert off.get_ndatapoints() == ref.get_ndatapoints() and off.get_ymean() == ref.get_ymean()
+    kern = make_kernel("RBF", ref.get_xdim(), 128, 123, "cuda", {})
+    kern.set_hyperparams(np.array([0.5, 0.7]), logspace=False)
+    w0, n0, _ = cg_fit_lib_internal(kern, off, 1e-8, 200, None, False, cache_features=False)
+    w1, n1, _ = cg_fit_lib_internal(kern, ref, 1e-8, 200, None, False, cache_features=False)
+    assert n0 == n1 and torch.equal(w0, w1)

@@ -77,3 +77,43 @@ def test_shard_bounds_cover_rows():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_offline_dataset_streams_npy_chunk_files(tmp_path):
+    """build_offline_np_dataset (reference data_handling/dataset_builder.py:193-340): a list of .npy chunk
+    files ends up as the same shard, y statistics and chunks as the in-memory builder, and the reference's
+    validation errors are raised."""
+    from xgpr_amd.dataset import build_offline_np_dataset, build_regression_dataset
+    rng = np.random.default_rng(3)
+    xs, ys, xf, yf = [], [], [], []
+    for i, n in enumerate((50, 17, 64)):
+        x, y = rng.standard_normal((n, 9)), rng.standard_normal(n) * 3 + 1
+        np.save(tmp_path / f"x{i}.npy", x)
+        np.save(tmp_path / f"y{i}.npy", y)
+        xs.append(x), ys.append(y), xf.append(str(tmp_path / f"x{i}.npy")), yf.append(str(tmp_path / f"y{i}.npy"))
+    off = build_offline_np_dataset(xf, yf, chunk_size=64, device="cpu")
+    ref = build_regression_dataset(np.vstack(xs), np.concatenate(ys), chunk_size=64, device="cpu")
+    assert off.get_ndatapoints() == 131 and off.get_xdim() == ref.get_xdim()
+    assert off.get_ymean() == ref.get_ymean() and off.get_ystd() == ref.get_ystd()
+    for (xa, ya, _), (xb, yb, _) in zip(off.get_chunked_data(), ref.get_chunked_data()):
+        assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    with pytest.raises(RuntimeError):
+        build_offline_np_dataset(xf, yf[:2], device="cpu")
+    with pytest.raises(RuntimeError):
+        build_offline_np_dataset(xf, yf, chunk_size=32, device="cpu")        # a file exceeds chunk_size
+    bad = rng.standard_normal((5, 9))
+    bad[2, 3] = np.nan
+    np.save(tmp_path / "xbad.npy", bad)
+    np.save(tmp_path / "ybad.npy", np.zeros(5))
+    with pytest.raises(RuntimeError):
+        build_offline_np_dataset(xf + [str(tmp_path / "xbad.npy")], yf + [str(tmp_path / "ybad.npy")],
+                                 chunk_size=64, device="cpu")
+    # classification labels
+    yi = [rng.integers(0, 3, size=x.shape[0]) for x in xs]
+    yi[0][:3] = [0, 1, 2]
+    yif = []
+    for i, y in enumerate(yi):
+        np.save(tmp_path / f"yi{i}.npy", y)
+        yif.append(str(tmp_path / f"yi{i}.npy"))
+    cls = build_offline_np_dataset(xf, yif, chunk_size=64, device="cpu", task_type="classification")
+    assert cls.get_n_classes() == 3 and cls.get_ndatapoints() == 131

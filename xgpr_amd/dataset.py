@@ -187,3 +187,112 @@ def build_classification_dataset(xdata, ydata, sequence_lengths=None, chunk_size
         raise RuntimeError("For classification, there must be a zero category.")
     return DeviceDataset(xt, yt, sl, chunk_size, 0.0, 1.0, int(round(count.item())), device, comm,
                          max_class=int(ext[0].item()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# On-disk datasets (data_handling/dataset_builder.py:193-340, offline_data_handling.py:73-108): lists of
+# .npy chunk files.  The reference re-reads every file on every pass; here the files of this rank (whole
+# files, round-robin over ranks) are streamed ONCE into the HBM-resident shard -- a loader thread reads
+# file i+1 from disk into pinned host memory while file i is copied to the device on a side stream -- and
+# everything downstream is the in-memory dataset.
+# ---------------------------------------------------------------------------------------------------
+def _check_offline_file(xfile, yfile, lfile, ndim, width, chunk_size):
+    x = np.load(xfile)
+    y = np.load(yfile)
+    if x.shape[0] == 0:
+        raise RuntimeError(f"File {xfile} has no datapoints.")
+    if np.isnan(x).any():
+        raise RuntimeError(f"One or more elements in file {xfile} is nan.")
+    if np.max(x) > 1e15 or np.min(x) < -1e15:
+        raise RuntimeError(f"One or more values in {xfile} is > 1e15 or < -1e15. Please check for inf values "
+                           "and / or rescale your data.")
+    if x.ndim != ndim:
+        raise RuntimeError(f"File {xfile} is not a {ndim}d array, unlike some other arrays in xlist.")
+    if tuple(x.shape[1:]) != tuple(width):
+        raise RuntimeError("All x arrays must have the same dimensionality.")
+    if x.shape[0] != y.shape[0]:
+        raise RuntimeError(f"File {xfile} has a different number of datapoints than file {yfile}.")
+    if x.shape[0] > chunk_size:
+        raise RuntimeError(f"Xfile {xfile} has more datapoints than allowed based on specified chunk_size.")
+    if y.ndim > 1:
+        raise RuntimeError(f"The y file {yfile} is not a 1d array.")
+    sl = None
+    if lfile is not None:
+        sl = np.load(lfile)
+        if sl.shape[0] != x.shape[0] or sl.max() > x.shape[1] or sl.min() < 1:
+            raise RuntimeError(f"The sequence lengths in {lfile} do not match {xfile}.")
+    return x, y, sl
+
+
+def build_offline_np_dataset(xlist, ylist, sequence_lengths=None, chunk_size=2000, device="cuda", comm=SINGLE,
+                             task_type="regression", prefetch_depth=2):
+    """dataset_builder.py:193-340 for lists of .npy files (one chunk per file, each <= chunk_size rows)."""
+    import queue
+    import threading
+    if not isinstance(xlist, list) or not isinstance(ylist, list):
+        raise RuntimeError("Both xlist and ylist should be lists.")
+    if len(xlist) == 0:
+        raise RuntimeError("At least one datafile must be supplied.")
+    if len(xlist) != len(ylist):
+        raise RuntimeError("xlist and ylist must have the same length.")
+    if sequence_lengths is not None and len(sequence_lengths) != len(ylist):
+        raise RuntimeError("sequence_lengths must either be None or have the same length as ylist.")
+    lfiles = sequence_lengths if sequence_lengths is not None else [None] * len(ylist)
+    first = np.load(xlist[0], mmap_mode="r")
+    ndim, width = first.ndim, first.shape[1:]
+    if ndim not in (2, 3):
+        raise RuntimeError("Arrays should be either 2d or 3d.")
+    mine = list(range(comm.rank, len(xlist), comm.world_size))      # whole files, round-robin over ranks
+    rows = [np.load(xlist[i], mmap_mode="r").shape[0] for i in mine]
+    n_local = int(sum(rows))
+    is_cuda = torch.device(device).type == "cuda"
+    xt = torch.empty((n_local,) + tuple(width), dtype=torch.float32, device=device)
+    ydtype = torch.float64 if task_type == "regression" else torch.int64
+    yt = torch.empty(n_local, dtype=ydtype, device=device)
+    sl_all = np.empty(n_local, dtype=np.int32) if sequence_lengths is not None else None
+
+    q = queue.Queue(maxsize=max(1, prefetch_depth))
+
+    def loader():
+        try:
+            for i in mine:
+                x, y, sl = _check_offline_file(xlist[i], ylist[i], lfiles[i], ndim, width, chunk_size)
+                if task_type == "classification" and not np.issubdtype(y.dtype, np.integer):
+                    raise RuntimeError("For classification, there must be a zero category, and all yfiles "
+                                       "must be integers.")
+                xh = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+                yh = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64 if task_type == "regression" else np.int64))
+                if is_cuda:
+                    xh, yh = xh.pin_memory(), yh.pin_memory()
+                q.put((xh, yh, sl))
+            q.put(None)
+        except Exception as err:      # surface loader errors in the caller's thread
+            q.put(err)
+
+    th = threading.Thread(target=loader, daemon=True)
+    th.start()
+    copy_stream = torch.cuda.Stream(device=device) if is_cuda else None
+    row = 0
+    while True:
+        item = q.get()
+        if item is None:
+            break
+        if isinstance(item, Exception):
+            raise item
+        xh, yh, sl = item
+        j = row + xh.shape[0]
+        if is_cuda:
+            with torch.cuda.stream(copy_stream):
+                xt[row:j].copy_(xh, non_blocking=True)
+                yt[row:j].copy_(yh, non_blocking=True)
+            copy_stream.synchronize()         # the pinned buffers are released when xh / yh go out of scope
+        else:
+            xt[row:j] = xh
+            yt[row:j] = yh
+        if sl_all is not None:
+            sl_all[row:j] = sl.astype(np.int32)
+        row = j
+    th.join()
+    if task_type == "classification":
+        return build_classification_dataset(xt, yt, sl_all, chunk_size, device, comm, already_sharded=True)
+    return build_regression_dataset(xt, yt, sl_all, chunk_size, device, comm, already_sharded=True)
