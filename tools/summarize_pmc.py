@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs of tools/collect_profiles.sh (merged into gpurun_out/) into the committed
+summaries under profiles/: kernel stats of the bench command, the FETCH_SIZE / WRITE_SIZE rows of the bench's
+dominant kernels, and the per-launch HBM traffic JSONs bench.py reads.  gfx950 correction (MI355X_MICROARCH.md,
+HBM section): FETCH_SIZE tallies 64 B per 128-B request for wide streaming reads, so it is doubled; WRITE_SIZE is
+taken as reported.  Counter units are KiB."""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+ROUND = "r1"
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(G, pattern))
+    if not f:
+        sys.exit(f"missing {pattern}")
+    return f[0]
+
+
+shutil.copy(one("prof_stats/*/*kernel_stats.csv"), os.path.join(P, f"{ROUND}_bench_n1_kernel_stats.csv"))
+KERNELS = {"wave_ztz_kernel": "fused", "zcache_ztz_kernel": "cached", "zblock_t_kernel": "block_t", "zblock_w_kernel": "block_w",
+           "reduce_slabs_kernel": "reduce", "wave_rbf_kernel": "featgen"}
+per = {}
+for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    rows = [r for r in csv.DictReader(open(one(f"prof_{tag}/*/*counter_collection.csv")))
+            if any(k in r["Kernel_Name"] for k in KERNELS) and r["Counter_Name"] == counter]
+    keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+            "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(os.path.join(P, f"{ROUND}_bench_n1_pmc_{tag}_size.csv"), "w", newline="") as fo:
+        w = csv.DictWriter(fo, keep)
+        w.writeheader()
+        for r in rows:
+            d = {k: r[k] for k in keep}
+            d["Kernel_Name"] = d["Kernel_Name"][:90]
+            w.writerow(d)
+    for r in rows:
+        for k, short in KERNELS.items():
+            if k in r["Kernel_Name"]:
+                per.setdefault(short, {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+bench = json.loads(open(os.path.join(G, "prof_fetch.json")).read().strip().splitlines()[-1])
+n_local, d, m = bench["config"]["rows_per_gpu"], 1024, 8192
+
+
+def mean_main(vals):
+    """mean over the launches of the full-size problem (the largest values; short probe launches are dropped)"""
+    top = max(vals)
+    sel = [v for v in vals if v > 0.5 * top]
+    return sum(sel) / len(sel)
+
+
+note = ("gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; "
+        "separate --pmc passes with --kernel-trace only (tools/collect_profiles.sh)")
+for short, kname, alg in (("fused", "wave_ztz_kernel<10, true, true>", 4.0 * d * n_local),
+                          ("cached", "zcache_ztz_kernel<true, 2>", 4.0 * m * n_local)):
+    if short not in per:
+        continue
+    fk, wk = mean_main(per[short]["FETCH_SIZE"]), mean_main(per[short]["WRITE_SIZE"])
+    hbm = (2.0 * fk + wk) * 1024.0
+    out = {"round": 1, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
+           "--steps 3 --warmup 1 --no-cpu-baseline", "kernel": kname,
+           "config": {"rows_per_gpu": n_local, "dim": d, "rffs": m, "n_gpus": 1},
+           "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk, "correction": note,
+           "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg}
+    name = f"{ROUND}_pmc_traffic.json" if short == "fused" else f"{ROUND}_pmc_traffic_cached.json"
+    json.dump(out, open(os.path.join(P, name), "w"), indent=1)
+    print(short, f"traffic/algorithmic = {hbm / alg:.4f}")
+for short in ("block_t", "block_w"):
+    if short in per:
+        fk, wk = mean_main(per[short]["FETCH_SIZE"]), mean_main(per[short]["WRITE_SIZE"])
+        print(short, f"HBM bytes per launch {(2 * fk + wk) * 1024 / 1e9:.2f} GB (cache read algorithmic {4.0 * m * n_local / 1e9:.2f} GB)")

@@ -1223,7 +1223,8 @@ struct ZbArgs {
     double tscale;       // factor applied to T at the store (1 inside the fused matvec, scale for the projection)
 };
 
-constexpr int ZB_FEATS = 16;      // features per LDS chunk of V (T kernel)
+constexpr int ZB_FEATS = 32;      // features per LDS chunk of V (T kernel): a lane's two loads per row tile cover whole 128-B lines
+                                  // (with 16 the other half of each line was fetched from HBM a second time: PMC traffic 2.0x)
 constexpr int ZB_ROWS = 32;       // datapoints per LDS chunk of T (W kernel)
 constexpr int ZB_RING = 4;        // chunks of the streamed operand per wave: ZB_RING - 1 in flight, one consumed
 constexpr int ZB_WFEATS = 512;    // features per workgroup of the W kernel (8 waves x 64)
@@ -1238,7 +1239,7 @@ __device__ __forceinline__ double elem(const float4 &v, int e) {
 }
 
 template <int CT, int ZB_RT>
-__global__ __launch_bounds__(512, 1) void zblock_t_kernel(ZbArgs a) {
+__global__ __launch_bounds__(512, ZB_RT == 1 ? 2 : 1) void zblock_t_kernel(ZbArgs a) {
     constexpr int KP = 16 * CT;
     constexpr int VS = KP + 4;                     // +32 B per row: lane groups g and g+1 land 128 B apart
     constexpr int QG = ZB_FEATS / 16;              // groups of 16 features per chunk
