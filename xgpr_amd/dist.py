@@ -57,6 +57,11 @@ def init_from_env(device_type="cuda"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal aids for a one-GPU box (several ranks sharing device 0 over gloo, which stages CUDA tensors
+    # through the host): XGPR_LOCAL_DEVICE pins the device index, XGPR_DIST_BACKEND picks the backend.
+    # Production runs set neither: one GPU per rank, RCCL.
+    if "XGPR_LOCAL_DEVICE" in os.environ:
+        local = int(os.environ["XGPR_LOCAL_DEVICE"])
     if device_type == "cuda":
         torch.cuda.set_device(local)
     if world == 1:
@@ -64,9 +69,9 @@ def init_from_env(device_type="cuda"):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if not dist.is_initialized():
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        backend = os.environ.get("XGPR_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         kwargs = {}
-        if device_type == "cuda":
+        if device_type == "cuda" and backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return Comm(rank, world)
