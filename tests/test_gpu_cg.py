@@ -284,3 +284,24 @@ def test_conv_preconditioned_cg_sharing_one_feature_pass_matches_oracle(oracle, 
     wref, nref, _, _ = orc.cg_fit_lib_internal(okern, ods, 1e-9, 300, opre)
     assert abs(niter - nref) <= 1
     assert rel(w, wref) < 1e-5
+
+
+def test_resident_cache_beyond_8192_frequencies_uses_block_contractions():
+    """num_freqs = 16384 (BASELINE cfg5's M = 32768): the k = 1 streaming kernel does not apply, the resident
+    cache goes through the two block contractions with one column; same solve as the two-pass regenerating
+    matvec."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import cg_fit_lib_internal
+    rng = np.random.default_rng(9)
+    n, d, m = 700, 40, 32768
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    y = np.sin(x @ rng.standard_normal(d)) + 0.1 * rng.standard_normal(n)
+    ds = build_regression_dataset(x, y, chunk_size=256, device=DEV)
+    kern = make_kernel("RBF", x.shape, m, 123, DEV, {})
+    kern.set_hyperparams(np.array([0.8, 0.5]), logspace=False)
+    assert kern.cache_ok() and kern.num_freqs > 8192
+    w0, n0, _ = cg_fit_lib_internal(kern, ds, 1e-9, 300, None, False, cache_features=False)
+    w1, n1, _ = cg_fit_lib_internal(kern, ds, 1e-9, 300, None, False, cache_features=True)
+    assert abs(n0 - n1) <= 1
+    assert rel(w1, w0.cpu().numpy()) < 1e-7

@@ -156,7 +156,9 @@ class SORFKernel(KernelBase):
     # it on every CG iteration instead of regenerating it (an option the 288 GB of HBM3E allow;
     # the reference cannot hold Z and regenerates it, cg_tools.py:189-191)
     def cache_ok(self):
-        return self.fused_ok() and self.num_freqs <= 8192
+        """k = 1 streaming kernel up to num_freqs = 8192 (a workgroup holds all tiles of a datapoint); beyond
+        that the resident cache is applied through the two block contractions with one column."""
+        return self.fused_ok() and (self.num_freqs <= 8192 or self.block_ok())
 
     def build_feature_cache(self, dataset):
         x_scaled = dataset.scaled_x(self.hyperparams[1])
@@ -165,7 +167,13 @@ class SORFKernel(KernelBase):
         return zc
 
     def ztz_matvec_cached(self, zcache, vec, out, workspace):
-        ext.hipZCacheMatvec(zcache, vec, out, self.fit_intercept, workspace)
+        if self.num_freqs <= 8192:
+            ext.hipZCacheMatvec(zcache, vec, out, self.fit_intercept, workspace)
+            return
+        need = block_workspace_bytes(zcache.shape[0], self.num_rffs, 1)
+        if getattr(self, "_cache_bws", None) is None or self._cache_bws.numel() < need:
+            self._cache_bws = torch.empty(need, dtype=torch.uint8, device=zcache.device)
+        ext.hipZCacheBlockMatvec(zcache, vec[:, None], out[:, None], self.fit_intercept, self._cache_bws)
 
     # ---- block of right-hand sides (approximate-NMLL probes, k = 26): float64 matrix cores over
     # the float32 cache, either the resident one or a window of rows regenerated into scratch
