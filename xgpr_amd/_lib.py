@@ -66,6 +66,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64 and must be the HIP runtime of the process; loading this
+    # library before torch would bind it to the system copy, and the second runtime then sees no device
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "
