@@ -27,11 +27,17 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build libxgpr_hip.so")
 
 
+def sources():
+    """xgpr_hip.hip is one translation unit that includes the .inc files next to it."""
+    csrc = os.path.dirname(SRC)
+    return [SRC, HDR] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".inc"))
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in (SRC, HDR))
+    return any(os.path.getmtime(p) > t for p in sources())
 
 
 def build_extension(force=False, verbose=False):
