@@ -112,3 +112,54 @@ def test_cfg2_cg_solve_residual():
     ConjugateGrad()._matvec(ds, k, w[:, None].contiguous(), aw)
     resid = float(torch.linalg.norm(aw[:, 0] - zty) / torch.linalg.norm(zty))
     assert resid < 1e-5, resid
+
+
+def test_block_matvec_properties_at_cfg3_size():
+    """The matrix-core block matvec at BASELINE cfg3 width (262 144 rows x 8192 RFFs, 26 columns), through
+    size-independent properties: additivity over a split of the datapoints (accumulate), agreement of single
+    columns with the k = 1 streaming kernel, linearity in V, determinism."""
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    n, m, k = 262144, 8192, 26
+    g = torch.Generator(device=DEV).manual_seed(11)
+    zc = torch.rand(n, m, dtype=torch.float32, device=DEV, generator=g) * 2 - 1
+    v = torch.randn(m, k, dtype=torch.float64, device=DEV, generator=g)
+    ws = torch.empty(ext.zcache_block_workspace_bytes(n, m, k), dtype=torch.uint8, device=DEV)
+    w_all = torch.empty_like(v)
+    ext.hipZCacheBlockMatvec(zc, v, w_all, True, ws)
+    cut = 100003                                          # ragged split
+    w_split = torch.empty_like(v)
+    ext.hipZCacheBlockMatvec(zc[:cut], v, w_split, True, ws)
+    ext.hipZCacheBlockMatvec(zc[cut:], v, w_split, True, ws, accumulate=True)
+    assert ((w_split - w_all).abs().max() / w_all.abs().max()).item() < 1e-13
+    ws1 = torch.empty(ext.ztz_workspace_bytes(m, m // 2), dtype=torch.uint8, device=DEV)
+    w1 = torch.empty(m, dtype=torch.float64, device=DEV)
+    for col in (0, 25):
+        ext.hipZCacheMatvec(zc, v[:, col].contiguous(), w1, True, ws1)
+        assert ((w_all[:, col] - w1).abs().max() / w1.abs().max()).item() < 1e-13
+    w_lin = torch.empty_like(v)
+    ext.hipZCacheBlockMatvec(zc, 3.0 * v, w_lin, True, ws)
+    assert ((w_lin - 3.0 * w_all).abs().max() / w_all.abs().max()).item() < 1e-14
+    w_again = torch.empty_like(v)
+    ext.hipZCacheBlockMatvec(zc, v, w_again, True, ws)
+    assert torch.equal(w_again, w_all)
+
+
+def test_approximate_nmll_within_one_percent_of_exact_at_moderate_size():
+    """The reference's acceptance criterion for the SLQ approximation (its test_slq_nmll.py:73-79: within 1 %
+    of the exact NMLL) on a synthetic problem 50x larger than its fixture, with the block matvec taking the
+    regenerated-window path and the resident-cache path."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd import nmll
+    rng = np.random.default_rng(12)
+    n, d, m = 20000, 64, 2048
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    y = np.sin(x @ rng.standard_normal(d)) + 0.2 * rng.standard_normal(n)
+    ds = build_regression_dataset(x, y, chunk_size=4096, device=DEV)
+    kern = make_kernel("Matern", x.shape, m, 123, DEV, {"matern_nu": 2.5})
+    kern.set_hyperparams(np.array([np.log(0.5), np.log(0.3)]), logspace=True)
+    exact = nmll.exact_nmll(kern, ds)
+    vals = [nmll.approximate_nmll(kern, ds, None, {"max_rank": 256, "nsamples": 25}, 123, cache_features=c)
+            for c in (False, True)]
+    assert abs(vals[0] - vals[1]) <= 1e-9 * abs(vals[0])
+    assert 100 * abs(vals[0] - exact) / abs(exact) < 1.0
