@@ -101,3 +101,32 @@ def test_classifier_conv_kernel_matches_oracle(oracle):
     assert niter == nref
     assert np.allclose(losses, lossref, rtol=1e-5)
     assert rel(w, wref) < 1e-4
+
+
+def test_classifier_cost_with_more_than_32_classes(oracle):
+    """More classes than one call of the block operators takes (32 columns): the cost function walks column
+    groups; gradient and loss against the oracle."""
+    from oracle import oracle as orc
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_classification_dataset
+    from xgpr_amd.classification import NonlinearCGClassification, predict_proba
+    rng = np.random.default_rng(41)
+    n, d, m, ncls = 900, 10, 128, 40
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    y = rng.integers(0, ncls, size=n).astype(np.int64)
+    y[:ncls] = np.arange(ncls)
+    hp = np.array([0.7, 0.9])
+    ds = build_classification_dataset(x, y, chunk_size=256, device=DEV)
+    kern = make_kernel("RBF", x.shape, m, 123, DEV, {})
+    kern.set_hyperparams(hp, logspace=False)
+    w0 = 0.2 * rng.standard_normal((m, ncls))
+    for cache in (False, True):
+        op = NonlinearCGClassification(ds, kern, False, None, cache_features=cache)
+        grad, loss = op.cost_fun_classification(torch.from_numpy(w0).to(DEV))
+        ods = orc.OracleClassificationDataset(x.astype(np.float64), y, chunk_size=256)
+        okern = orc.OracleKernel("RBF", m, x.shape, hp, 123, ops=oracle)
+        gref, lref = orc.classification_cost(ods, okern, w0)
+        assert np.isclose(loss, lref, rtol=1e-6) and rel(grad, gref) < 1e-5
+    probs = predict_proba(kern, torch.from_numpy(w0).to(DEV), torch.zeros(ncls, dtype=torch.float64, device=DEV),
+                          torch.from_numpy(x[:50]).to(DEV))
+    assert np.allclose(probs.cpu().numpy(), orc.predict_proba(okern, w0, x[:50].astype(np.float64)), rtol=1e-5, atol=1e-7)
