@@ -318,8 +318,9 @@ def main():
             "roofline": {"kernel": "wave_ztz_kernel<10, true> (+ pack_radem, reduce_slabs)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
-                         "note": "HBM traffic of this kernel is only the X read; the binding resource is VALU "
-                                 "(butterflies + sincos), see DESIGN.md"},
+                         "note": "HBM traffic of this kernel is only the X read; the binding resources are the vector pipe "
+                                 "(butterflies + sincos; 64 % busy at 2 waves/SIMD) and LDS-exchange latency: "
+                                 "profiles/r1_fused_pmc_sq.json, DESIGN.md section 3"},
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},
