@@ -948,3 +948,59 @@ def predict_proba(kernel, weights, input_x, sequence_lengths=None, gamma=None):
     if gamma is not None:
         pred = pred + gamma[None, :]
     return _softmax_ref(pred)
+
+
+# ---------------------------------------------------------------------------------------
+# Preconditioner rank selection (model_baseclass.py:376-480, rand_nys_constructors.py:60-93, :301-357)
+# ---------------------------------------------------------------------------------------
+def srht_ratio_check(dataset, rank, kernel, random_state=123, sample_frac=0.1):
+    """rand_nys_constructors.py:301-357 with the sampled pass of :60-93."""
+    m = kernel.get_num_rffs()
+    acc = np.zeros((rank, m))
+    comp = OracleSRHTCompressor(rank, m, random_seed=random_state, ops=kernel.ops)
+    rng = np.random.default_rng(random_state)
+    for xd, ld in dataset.get_chunked_x_data():
+        cutoff = max(int(sample_frac * float(xd.shape[0])), 1)
+        idx = rng.permutation(xd.shape[0])[:cutoff]
+        z = kernel.transform_x(xd[idx, ...], None if ld is None else ld[idx])
+        acc += comp.transform_x(z).T @ z
+    c_mat = comp.transform_x(acc)
+    _, s1, v1 = np.linalg.svd(c_mat, full_matrices=False)
+    mask = s1 < 1e-14
+    s1 = 1 / np.sqrt(s1.clip(min=1e-14))
+    s1[mask] = 0
+    acc = acc.T @ v1.T @ (s1[:, None] * v1)
+    _, s_mat, _ = np.linalg.svd(acc, full_matrices=False)
+    return s_mat ** 2
+
+
+def check_rank_ratio(kernel, dataset, sample_frac=0.1, max_rank=512, random_seed=123):
+    """model_baseclass.py:438-480 (kernels of at most 8192 random features)."""
+    s_mat = srht_ratio_check(dataset, max_rank, kernel, random_seed, sample_frac)
+    return float(s_mat.min() / kernel.get_lambda() ** 2) / sample_frac
+
+
+def autoselect_rank(kernel, dataset, min_rank=512, max_rank=3000, increment_size=512, always_use_srht2=False,
+                    ratio_target=30., random_seed=123):
+    """model_baseclass.py:376-436 -> (rank, method) the preconditioner is then built with."""
+    sample_frac, method, ratio, rank = 0.2, "srht", np.inf, min_rank
+    m = kernel.get_num_rffs()
+    if rank >= m:
+        rank = m - 1
+        ratio = 0.5 * ratio_target
+    if dataset.get_ndatapoints() < 5000:
+        sample_frac = 1
+    while ratio > ratio_target and rank < max_rank:
+        ratio = check_rank_ratio(kernel, dataset, sample_frac, rank, random_seed)
+        if ratio > ratio_target:
+            if (rank + increment_size) < max_rank and (rank + increment_size) < m:
+                rank += increment_size
+            else:
+                rank = max_rank
+                if rank > m:
+                    rank = m - 1
+                method = "srht_2"
+                break
+    if always_use_srht2:
+        method = "srht_2"
+    return rank, method

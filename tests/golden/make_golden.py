@@ -514,6 +514,32 @@ def g12_mini_ard(xgpr):
     save("g12_mini_ard.npz", **out)
 
 
+def g13_rank_selection(xgpr):
+    """Preconditioner rank selection on the reference fixture (model_baseclass.py:376-480,
+    rand_nys_constructors.py:60-93, :301-357): the sampled ratio for a few (sample_frac, rank) pairs and the
+    rank / achieved ratio the autoselection ends with for two ratio targets."""
+    from xGPR import xGPRegression
+    from xGPR.data_handling.dataset_builder import build_regression_dataset
+    xtr = np.load(os.path.join(REF_TESTDATA, "0_block_trainxvalues.npy"))
+    ytr = np.load(os.path.join(REF_TESTDATA, "0_block_trainyvalues.npy"))
+    ds = build_regression_dataset(xtr, ytr, chunk_size=100)
+    hparam = np.array([np.log(np.sqrt(0.0767)), np.log(0.358)])
+    mod = xGPRegression(num_rffs=512, kernel_choice="RBF", variance_rffs=12, random_seed=123, device="cpu",
+                        kernel_settings={"intercept": True}, verbose=False)
+    mod.set_hyperparams(hparam, ds)
+    out = {"hparam_log": hparam, "chunk_size": np.int64(100)}
+    fr, rk, ratios = [], [], []
+    for sample_frac, rank in ((1.0, 32), (0.5, 32), (0.25, 64), (1.0, 128)):
+        fr.append(sample_frac), rk.append(rank)
+        ratios.append(mod._check_rank_ratio(ds, sample_frac=sample_frac, max_rank=rank))
+    out["sample_fracs"], out["ranks"], out["ratios"] = np.asarray(fr), np.asarray(rk), np.asarray(ratios)
+    for tag, target in (("t30", 30.), ("t3", 3.)):
+        pre = mod._autoselect_preconditioner(ds, min_rank=16, max_rank=200, increment_size=48, ratio_target=target)
+        out[f"{tag}_rank"] = np.int64(pre.u_mat.shape[1])
+        out[f"{tag}_achieved_ratio"] = np.float64(pre.achieved_ratio)
+    save("g13_rank_selection.npz", **out)
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -528,3 +554,4 @@ if __name__ == "__main__":
     g10_nmll(xgpr)
     g11_classifier(xgpr)
     g12_mini_ard(xgpr)
+    g13_rank_selection(xgpr)

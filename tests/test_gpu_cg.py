@@ -305,3 +305,23 @@ def test_resident_cache_beyond_8192_frequencies_uses_block_contractions():
     w1, n1, _ = cg_fit_lib_internal(kern, ds, 1e-9, 300, None, False, cache_features=True)
     assert abs(n0 - n1) <= 1
     assert rel(w1, w0.cpu().numpy()) < 1e-7
+
+
+def test_g13_rank_selection_vs_reference():
+    """check_rank_ratio / autoselect_preconditioner on the device against the reference's values
+    (tests/golden/g13_rank_selection.npz)."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import check_rank_ratio, autoselect_preconditioner
+    g8, g = load_golden("g8_e2e.npz"), load_golden("g13_rank_selection.npz")
+    x, y = g8["xtrain"], g8["ytrain"]
+    ds = build_regression_dataset(x, y, chunk_size=int(g["chunk_size"]), device=DEV)
+    kern = make_kernel("RBF", x.shape, 512, 123, DEV, {"intercept": True})
+    kern.set_hyperparams(g["hparam_log"], logspace=True)
+    for frac, rank, ratio in zip(g["sample_fracs"], g["ranks"], g["ratios"]):
+        assert np.isclose(check_rank_ratio(kern, ds, float(frac), int(rank), 123), float(ratio), rtol=1e-4)
+    for tag, target in (("t30", 30.), ("t3", 3.)):
+        pre, rank, method = autoselect_preconditioner(kern, ds, min_rank=16, max_rank=200, increment_size=48,
+                                                      ratio_target=target, random_seed=123)
+        assert rank == int(g[f"{tag}_rank"]) and pre.get_rank() == rank
+        assert np.isclose(pre.achieved_ratio, float(g[f"{tag}_achieved_ratio"]), rtol=1e-4)

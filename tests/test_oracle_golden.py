@@ -292,3 +292,19 @@ def test_g12_mini_ard_oracle_vs_reference_ground_truth(oracle):
                 ref_f[:, 0] = 1.0
             assert np.allclose(feats, ref_f, rtol=rtol_f, atol=atol_f)     # tolerances of the reference's test (:77-80)
             assert np.allclose(grad, ref_g, rtol=rtol_g, atol=atol_g)
+
+
+def test_g13_rank_selection_oracle_vs_reference(oracle):
+    """Sampled rank / ratio check and the rank autoselection (reference model_baseclass.py:376-480,
+    rand_nys_constructors.py:60-93, :301-357) against the reference's own values on its fixture."""
+    g8, g = load_golden("g8_e2e.npz"), load_golden("g13_rank_selection.npz")
+    x, y = g8["xtrain"], g8["ytrain"]
+    ds = orc.OracleDataset(x, y, chunk_size=int(g["chunk_size"]))
+    kern = orc.OracleKernel("RBF", 512, x.shape, np.exp(g["hparam_log"]), 123, ops=oracle)
+    for frac, rank, ratio in zip(g["sample_fracs"], g["ranks"], g["ratios"]):
+        assert np.isclose(orc.check_rank_ratio(kern, ds, float(frac), int(rank), 123), float(ratio), rtol=1e-6)
+    for tag, target in (("t30", 30.), ("t3", 3.)):
+        rank, method = orc.autoselect_rank(kern, ds, 16, 200, 48, False, target, 123)
+        assert rank == int(g[f"{tag}_rank"])
+        pre = orc.OracleRandNysPreconditioner(kern, ds, rank, 123, method)
+        assert np.isclose(pre.achieved_ratio, float(g[f"{tag}_achieved_ratio"]), rtol=1e-6)

@@ -45,6 +45,8 @@ class KernelBase:
                                "fourier features must be an integer multiple of two.")
         self.num_freqs = int(num_rffs / 2)
         self.num_rffs = int(num_rffs)
+        self.kernel_spec_parms = dict(kernel_spec_parms)
+        self.random_seed = 123           # subclasses overwrite it with the seed they draw with
         self.fit_intercept = kernel_spec_parms.get("intercept", True) is not False
         self._xdim = tuple(xdim)
         self.hyperparams = np.ones((2))
@@ -114,6 +116,7 @@ class SORFKernel(KernelBase):
                  kernel_spec_parms=None):
         kernel_spec_parms = kernel_spec_parms or {}
         super().__init__(num_rffs, xdim, kernel_spec_parms, device)
+        self.random_seed = random_seed
         if len(xdim) != 2:
             raise ValueError("The dimensionality of the input is inappropriate for "
                              "the kernel you have selected.")
@@ -254,6 +257,7 @@ class ConvSORFKernel(KernelBase):
                  kernel_spec_parms=None):
         kernel_spec_parms = kernel_spec_parms or {}
         super().__init__(num_rffs, xdim, kernel_spec_parms, device)
+        self.random_seed = random_seed
         if len(xdim) != 3:
             raise RuntimeError("Tried to initialize a Conv1d kernel with a 2d x-"
                                "array! x should be a 3d array for Conv1d.")
@@ -360,6 +364,7 @@ class MiniARDKernel(KernelBase):
                  kernel_spec_parms=None):
         kernel_spec_parms = kernel_spec_parms or {}
         super().__init__(num_rffs, xdim, kernel_spec_parms, device)
+        self.random_seed = random_seed
         self.double_precision = double_precision
         if len(self._xdim) != 2:
             raise ValueError("The dimensionality of the input is inappropriate for "

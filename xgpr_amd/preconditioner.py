@@ -5,6 +5,8 @@
   * ``single_pass_gauss``           <-> rand_nys_constructors.py:18-36
   * ``initialize_srht``             <-> rand_nys_constructors.py:221-296
   * ``initialize_srht_multipass``   <-> rand_nys_constructors.py:127-218
+  * ``subsampled_srht`` / ``srht_ratio_check`` <-> rand_nys_constructors.py:60-93, :301-357
+  * ``check_rank_ratio`` / ``autoselect_preconditioner`` <-> model_baseclass.py:438-480, :376-436
 
 The accumulation passes run per chunk on the device (SORF feature generation and the SRHT of
 the chunk are HIP kernels of libxgpr_hip.so; the dense ``[rank x n] @ [n x M]`` float64
@@ -169,6 +171,78 @@ def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False
     u_mat, s_mat = _tall_svd(acc_results)
     s_mat = (s_mat ** 2 - shift).clip(min=0)
     return u_mat, s_mat, z_trans_y, y_trans_y
+
+
+def subsampled_srht(dataset, kernel, compressor, acc_results, verbose, sample_frac=0.1, random_seed=123):
+    """rand_nys_constructors.py:60-93: the SRHT accumulation pass over a random sample of every chunk (the
+    host draws the row indices with the reference's generator calls)."""
+    rng = np.random.default_rng(random_seed)
+    for j, (xdata, ldata) in enumerate(dataset.get_chunked_x_data()):
+        cutoff = max(int(sample_frac * float(xdata.shape[0])), 1)
+        idx = rng.permutation(xdata.shape[0])[:cutoff]
+        tidx = torch.from_numpy(idx).to(xdata.device)
+        zdata = kernel.transform_x(xdata[tidx, ...], None if ldata is None else ldata[idx])
+        acc_results += compressor.transform_x(zdata).T @ zdata
+        if j % 10 == 0 and verbose:
+            print(f"Chunk {j} complete.")
+
+
+def srht_ratio_check(dataset, rank, kernel, random_state, verbose=False, sample_frac=0.1):
+    """rand_nys_constructors.py:301-357 -> the eigenvalues of the Nystrom approximation built from the sample."""
+    acc_results = torch.zeros((rank, kernel.get_num_rffs()), dtype=torch.float64, device=kernel.device)
+    compressor = SRHTCompressor(rank, kernel.get_num_rffs(), device=kernel.device, random_seed=random_state)
+    subsampled_srht(dataset, kernel, compressor, acc_results, verbose, sample_frac, random_state)
+    dataset.comm.all_reduce_(acc_results)
+    c_mat = compressor.transform_x(acc_results)
+    acc_results = _inv_sqrt_apply(acc_results.T, c_mat)
+    _, s_mat = _tall_svd(acc_results)
+    return s_mat ** 2
+
+
+def check_rank_ratio(kernel, dataset, sample_frac=0.1, max_rank=512, random_seed=123, verbose=False):
+    """model_baseclass.py:438-480: min eigenvalue / lambda^2 / sample_frac for a preconditioner of rank
+    ``max_rank`` estimated from a sample; like the reference, kernels with more than 8192 random features are
+    checked with an 8192-feature kernel of the same family, seed and hyperparameters."""
+    if sample_frac < 0.01 or sample_frac > 1:
+        raise RuntimeError("sample_frac must be in the range [0.01, 1]")
+    check_kernel = kernel
+    if kernel.get_num_rffs() > 8192:
+        from .kernels import make_kernel
+        check_kernel = make_kernel(kernel.kernel_choice, dataset.get_xdim(), 8192, kernel.random_seed, kernel.device,
+                                   kernel.kernel_spec_parms)
+        check_kernel.set_hyperparams(kernel.get_hyperparams(logspace=False), logspace=False)
+    s_mat = srht_ratio_check(dataset, max_rank, check_kernel, random_seed, verbose, sample_frac)
+    return float(s_mat.min().item() / kernel.get_lambda() ** 2) / sample_frac
+
+
+def autoselect_preconditioner(kernel, dataset, min_rank=512, max_rank=3000, increment_size=512,
+                              always_use_srht2=False, ratio_target=30., random_seed=123, is_regression=True,
+                              verbose=False):
+    """model_baseclass.py:376-436: grow the rank until the sampled ratio drops below ``ratio_target`` (falling
+    back to a 2-pass build at ``max_rank``), then build the preconditioner -> (preconditioner, rank, method)."""
+    sample_frac, method, ratio, rank = 0.2, "srht", np.inf, min_rank
+    actual_num_rffs = kernel.get_num_rffs()
+    if rank >= actual_num_rffs:
+        rank = actual_num_rffs - 1
+        ratio = 0.5 * ratio_target
+    if dataset.get_ndatapoints() < 5000:
+        sample_frac = 1
+    while ratio > ratio_target and rank < max_rank:
+        ratio = check_rank_ratio(kernel, dataset, sample_frac, rank, random_seed, verbose)
+        if ratio > ratio_target:
+            if (rank + increment_size) < max_rank and (rank + increment_size) < actual_num_rffs:
+                rank += increment_size
+            else:
+                rank = max_rank
+                if rank > actual_num_rffs:
+                    rank = actual_num_rffs - 1
+                method = "srht_2"
+                break
+    if verbose:
+        print(f"Using rank: {rank}")
+    if always_use_srht2:
+        method = "srht_2"
+    return RandNysPreconditioner(kernel, dataset, rank, verbose, random_seed, method, is_regression), rank, method
 
 
 class RandNysPreconditioner:
