@@ -401,6 +401,59 @@ class OracleKernel:
         return out, grad
 
 
+class OracleTwoLayerKernel:
+    """kernels/convolution_kernels/l2_conv1d.py:16-222: max-pooled convolution features (cpuConv1dMaxpool),
+    scaled by sigma, into an RBF feature map (cpuRBFFeatureGen / cpuRBFGrad)."""
+
+    def __init__(self, num_rffs, xdim, hyperparams, conv_width, init_rffs, random_seed=123, fit_intercept=True, ops=None):
+        from scipy.stats import chi as _chi
+        self.ops = ops if ops is not None else Oracle()
+        self.num_rffs, self.num_freqs = num_rffs, num_rffs // 2
+        self.hyperparams = np.asarray(hyperparams, dtype=np.float64)
+        self.fit_intercept, self.conv_width, self.init_rffs = fit_intercept, conv_width, init_rffs
+        rng = np.random.default_rng(random_seed)
+        pd1 = padded_dims(conv_width * xdim[2])
+        radem_array = np.asarray([-1, 1], dtype=np.int8)
+        self.radem_diag1 = rng.choice(radem_array, size=(3, 1, ceil(init_rffs / pd1) * pd1), replace=True)
+        self.chi_arr1 = _chi.rvs(df=pd1, size=init_rffs, random_state=random_seed).astype(np.float32)
+        pd2 = padded_dims(init_rffs)
+        nblocks = ceil(self.num_freqs / pd2) if pd2 < self.num_freqs else 1
+        self.radem_diag2 = rng.choice(radem_array, size=(3, 1, nblocks * pd2), replace=True)
+        self.chi_arr2 = _chi.rvs(df=pd2, size=self.num_freqs, random_state=random_seed).astype(np.float32)
+
+    def get_lambda(self):
+        return self.hyperparams[0]
+
+    def get_num_rffs(self):
+        return self.num_rffs
+
+    def _first_layer(self, input_x, sequence_length):
+        xin = np.ascontiguousarray(input_x.astype(np.float32, copy=True))
+        feat = np.zeros((xin.shape[0], self.init_rffs), np.float32)
+        self.ops.cpuConv1dMaxpool(xin, feat, self.radem_diag1, self.chi_arr1,
+                                  sequence_length.astype(np.int32, copy=False), self.conv_width)
+        return feat
+
+    def transform_x(self, input_x, sequence_length=None):
+        feat = self._first_layer(input_x, sequence_length)
+        feat *= self.hyperparams[1]
+        out = np.zeros((feat.shape[0], self.num_rffs), np.float64)
+        self.ops.cpuRBFFeatureGen(feat, out, self.radem_diag2, self.chi_arr2, self.fit_intercept)
+        if self.fit_intercept:
+            out[:, 0] = 1.
+        return out
+
+    def gradient_x(self, input_x, sequence_length=None):
+        feat = self._first_layer(input_x, sequence_length)
+        out = np.zeros((feat.shape[0], self.num_rffs), np.float64)
+        grad = np.zeros((feat.shape[0], self.num_rffs, 1), np.float64)
+        self.ops.cpuRBFGrad(feat, out, grad, self.radem_diag2, self.chi_arr2, self.hyperparams[1], self.fit_intercept)
+        if self.fit_intercept:
+            out[:, 0] = 1.
+            grad[:, 0, :] = 0.
+        return out, grad
+
+
 class OracleMiniARDKernel:
     """kernels/ARD_kernels/mini_ard.py:16-287: one inverse lengthscale per group of input features.
     Features: the input scaled per feature, then the SORF operator (:171-194); gradient: dense

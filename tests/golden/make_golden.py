@@ -540,6 +540,24 @@ def g13_rank_selection(xgpr):
     save("g13_rank_selection.npz", **out)
 
 
+def g14_two_layer(xgpr):
+    """Conv1dTwoLayer (kernels/convolution_kernels/l2_conv1d.py): features and sigma-gradient from the
+    reference's kernel class on the compiled reference core, for ragged sequences."""
+    from xGPR.kernels.convolution_kernels.l2_conv1d import Conv1dTwoLayer
+    rng = np.random.default_rng(123)
+    n, L, C = 6, 24, 7
+    x = rng.uniform(-1, 1, size=(n, L, C))
+    sl = np.array([24, 9, 17, 5, 24, 12], dtype=np.int32)
+    hp = np.array([0.7, 0.35])
+    k = Conv1dTwoLayer((n, L, C), 128, 123, device="cpu", kernel_spec_parms={"conv_width": 5, "init_rffs": 96,
+                                                                              "intercept": True})
+    k.set_hyperparams(hp, logspace=False)
+    feats = k.transform_x(x, sl)
+    gfeats, grad = k.gradient_x(x, sl)
+    save("g14_two_layer.npz", x=x, seqlen=sl, hyperparams=hp, features=feats, grad_features=gfeats, grad=grad,
+         conv_width=np.int64(5), init_rffs=np.int64(96), num_rffs=np.int64(128))
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -555,3 +573,4 @@ if __name__ == "__main__":
     g11_classifier(xgpr)
     g12_mini_ard(xgpr)
     g13_rank_selection(xgpr)
+    g14_two_layer(xgpr)

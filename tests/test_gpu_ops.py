@@ -424,3 +424,21 @@ def test_srht_sample_equals_pad_srht_gather(oracle, n, m, rank):
     buf = torch.full((n, rank + 1), -7.0, dtype=torch.float64, device=DEV)
     view = comp.transform_x(zd, out=buf)
     assert torch.equal(view, fused) and bool((buf[:, rank] == -7.0).all())
+
+
+def test_g14_two_layer_kernel_vs_reference():
+    """Conv1dTwoLayer on the device (hipConv1dMaxpool -> sigma -> hipRBFFeatureGen / hipRBFGrad) against the
+    reference's kernel class (tests/golden/g14_two_layer.npz)."""
+    from xgpr_amd.kernels import make_kernel
+    g = load_golden("g14_two_layer.npz")
+    kern = make_kernel("Conv1dTwoLayer", g["x"].shape, int(g["num_rffs"]), 123, DEV,
+                       {"conv_width": int(g["conv_width"]), "init_rffs": int(g["init_rffs"]), "intercept": True})
+    kern.set_hyperparams(g["hyperparams"], logspace=False)
+    scale = np.sqrt(1.0 / (kern.num_freqs - 0.5))
+    feats = kern.transform_x(g["x"], g["seqlen"]).cpu().numpy()
+    assert np.abs(feats - g["features"]).max() <= 4e-7 * scale
+    f2, grad = kern.gradient_x(g["x"], g["seqlen"])
+    assert np.abs(f2.cpu().numpy() - g["grad_features"]).max() <= 4e-7 * scale
+    assert np.allclose(grad.cpu().numpy(), g["grad"], rtol=1e-5, atol=1e-5 * scale * np.abs(g["grad"]).max() / scale)
+    with pytest.raises(ValueError):
+        make_kernel("Conv1dTwoLayer", g["x"].shape, 128, 123, DEV, {"conv_width": 5})

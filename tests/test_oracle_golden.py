@@ -308,3 +308,14 @@ def test_g13_rank_selection_oracle_vs_reference(oracle):
         assert rank == int(g[f"{tag}_rank"])
         pre = orc.OracleRandNysPreconditioner(kern, ds, rank, 123, method)
         assert np.isclose(pre.achieved_ratio, float(g[f"{tag}_achieved_ratio"]), rtol=1e-6)
+
+
+def test_g14_two_layer_kernel_oracle_vs_reference(oracle):
+    """Conv1dTwoLayer (max-pooled convolution features into an RBF map): the oracle's kernel against the
+    reference's kernel class, features and sigma-gradient, ragged sequences."""
+    g = load_golden("g14_two_layer.npz")
+    k = orc.OracleTwoLayerKernel(int(g["num_rffs"]), g["x"].shape, g["hyperparams"], int(g["conv_width"]),
+                                 int(g["init_rffs"]), 123, True, ops=oracle)
+    assert np.array_equal(k.transform_x(g["x"], g["seqlen"]), g["features"])
+    f, gr = k.gradient_x(g["x"], g["seqlen"])
+    assert np.array_equal(f, g["grad_features"]) and np.array_equal(gr, g["grad"])

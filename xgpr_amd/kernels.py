@@ -353,6 +353,93 @@ class ConvSORFKernel(KernelBase):
         return xtrans
 
 
+class Conv1dTwoLayerKernel(KernelBase):
+    """kernels/convolution_kernels/l2_conv1d.py:16-222: a convolution layer with global max-pooling
+    (hipConv1dMaxpool: ``init_rffs`` ReLU'd random convolution filters per sequence) whose output feeds an RBF
+    kernel (hipRBFFeatureGen / hipRBFGrad); sigma scales the pooled features."""
+
+    def __init__(self, xdim, num_rffs, random_seed=123, device="cuda", kernel_spec_parms=None):
+        kernel_spec_parms = kernel_spec_parms or {}
+        if "conv_width" not in kernel_spec_parms:
+            raise ValueError("conv_width must be included as a kernel-specific "
+                             "parameter if using a sequence kernel.")
+        if "init_rffs" not in kernel_spec_parms:
+            raise ValueError("init_rffs must be included as a kernel-specific "
+                             "parameter if using the 2 layer conv1d kernel.")
+        if len(xdim) != 3:
+            raise RuntimeError("Tried to initialize a Conv1d kernel with a 2d x-"
+                               "array! x should be a 3d array for Conv1d.")
+        self.init_rffs = kernel_spec_parms["init_rffs"]
+        if self.init_rffs % 2 != 0:
+            raise RuntimeError("Number of init rffs should be an even number.")
+        super().__init__(num_rffs, xdim, kernel_spec_parms, device)
+        self.random_seed = random_seed
+        self.kernel_choice = "Conv1dTwoLayer"
+        rng = np.random.default_rng(random_seed)
+        self.conv_width = kernel_spec_parms["conv_width"]
+        pdims = padded_dims(self.conv_width * xdim[2])
+        init_calc_featsize = ceil(self.init_rffs / pdims) * pdims
+        radem_array = np.asarray([-1, 1], dtype=np.int8)
+        radem1 = rng.choice(radem_array, size=(3, 1, init_calc_featsize), replace=True)
+        chi1 = _chi.rvs(df=pdims, size=self.init_rffs, random_state=random_seed).astype(np.float32)
+        pdims2 = padded_dims(self.init_rffs)
+        nblocks = ceil(self.num_freqs / pdims2) if pdims2 < self.num_freqs else 1
+        radem2 = rng.choice(radem_array, size=(3, 1, nblocks * pdims2), replace=True)
+        chi2 = _chi.rvs(df=pdims2, size=self.num_freqs, random_state=random_seed).astype(np.float32)
+        self.radem_diag1 = torch.from_numpy(np.ascontiguousarray(radem1)).to(device)
+        self.chi_arr1 = torch.from_numpy(chi1).to(device)
+        self._to_device(radem2, chi2)            # radem_diag / chi_arr = the second (RBF) layer
+
+    supports_fused = False
+
+    def fused_ok(self):
+        return False
+
+    def _first_layer(self, input_x, sequence_length):
+        if sequence_length is None:
+            raise ValueError("sequence_length is required for convolution kernels.")
+        if input_x.shape[2] != self._xdim[2]:
+            raise RuntimeError("Unexpected input shape supplied.")
+        if isinstance(sequence_length, torch.Tensor):
+            sequence_length = sequence_length.cpu().numpy()
+        slen = np.ascontiguousarray(sequence_length.astype(np.int32, copy=False))
+        featurized_x = torch.zeros((input_x.shape[0], self.init_rffs), dtype=torch.float32, device=self.device)
+        ext.hipConv1dMaxpool(input_x, featurized_x, self.radem_diag1, self.chi_arr1, slen, self.conv_width)
+        return featurized_x
+
+    def transform_x(self, input_x, sequence_length=None):
+        """kernel_baseclass.py:269-299 with l2_conv1d.py:150-185."""
+        xin = self._as_device_f32(input_x).to(torch.float32, copy=True).contiguous()
+        featurized_x = scale_input(self._first_layer(xin, sequence_length), self.hyperparams[1])
+        xtrans = torch.zeros((featurized_x.shape[0], self.num_rffs), dtype=torch.float64, device=self.device)
+        ext.hipRBFFeatureGen(featurized_x, xtrans, self.radem_diag, self.chi_arr, self.fit_intercept)
+        if self.fit_intercept:
+            xtrans[:, 0] = 1.
+        return xtrans
+
+    def kernel_specific_gradient(self, input_x, sequence_length=None):
+        """l2_conv1d.py:189-222."""
+        featurized_x = self._first_layer(input_x, sequence_length)
+        output_x = torch.zeros((input_x.shape[0], self.num_rffs), dtype=torch.float64, device=self.device)
+        dz_dsigma = torch.zeros((input_x.shape[0], self.num_rffs, 1), dtype=torch.float64, device=self.device)
+        ext.hipRBFGrad(featurized_x, output_x, dz_dsigma, self.radem_diag, self.chi_arr,
+                       float(self.hyperparams[1]), self.fit_intercept)
+        return output_x, dz_dsigma
+
+    # the resident float32 cache holds complete feature rows, as for the other sequence kernels
+    def cache_ok(self):
+        return self.num_freqs <= 8192
+
+    def block_ok(self):
+        return self.num_rffs % 4 == 0
+
+    build_feature_cache = ConvSORFKernel.build_feature_cache
+    ztz_matvec_cached = ConvSORFKernel.ztz_matvec_cached
+    ztz_block_cached = ConvSORFKernel.ztz_block_cached
+    cache_rows_to_features = ConvSORFKernel.cache_rows_to_features
+    workspace_bytes = ConvSORFKernel.workspace_bytes
+
+
 class MiniARDKernel(KernelBase):
     """kernels/ARD_kernels/mini_ard.py:16-287: an RBF kernel with one inverse lengthscale per group of
     input features (groups delimited by ``split_points``).  hyperparams = [lambda, sigma_1 .. sigma_G].
@@ -484,8 +571,10 @@ def make_kernel(kernel_choice, xdim, num_rffs, random_seed=123, device="cuda", k
         return ConvSORFKernel(kernel_choice, xdim, num_rffs, random_seed, device, kernel_spec_parms)
     if kernel_choice == "MiniARD":
         return MiniARDKernel(xdim, num_rffs, random_seed, device, False, kernel_spec_parms)
+    if kernel_choice == "Conv1dTwoLayer":
+        return Conv1dTwoLayerKernel(xdim, num_rffs, random_seed, device, kernel_spec_parms)
     raise RuntimeError(f"kernel '{kernel_choice}' is outside the hot path this package implements "
-                       f"(supported: {_FIXED + _CONV + ('MiniARD',)})")
+                       f"(supported: {_FIXED + _CONV + ('MiniARD', 'Conv1dTwoLayer')})")
 
 
 class SRHTCompressor:
