@@ -325,3 +325,30 @@ def test_g13_rank_selection_vs_reference():
                                                       ratio_target=target, random_seed=123)
         assert rank == int(g[f"{tag}_rank"]) and pre.get_rank() == rank
         assert np.isclose(pre.achieved_ratio, float(g[f"{tag}_achieved_ratio"]), rtol=1e-4)
+
+
+def test_linear_kernel_fit_equals_ridge_regression():
+    """The Linear kernel (reference kernels/basic_kernels/linear.py): features are the float32-rounded input
+    plus an intercept column; the CG fit equals the closed-form ridge solution in float64."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import cg_fit_lib_internal
+    from xgpr_amd.exact import calc_weights_exact
+    rng = np.random.default_rng(51)
+    n, d = 3000, 37
+    x = rng.standard_normal((n, d))
+    y = x @ rng.standard_normal(d) + 0.3 * rng.standard_normal(n) + 2.0
+    ds = build_regression_dataset(x, y, chunk_size=700, device=DEV)
+    kern = make_kernel("Linear", x.shape, None, 123, DEV, {})
+    assert kern.get_num_rffs() == d + 1
+    lam = 0.37
+    kern.set_hyperparams(np.array([lam]), logspace=False)
+    z = kern.transform_x(x[:5]).cpu().numpy()
+    assert np.array_equal(z[:, 1:], x[:5].astype(np.float32).astype(np.float64)) and np.all(z[:, 0] == 1.0)
+    w, niter, _ = cg_fit_lib_internal(kern, ds, 1e-12, 500, None, False, cache_features=False)
+    zf = np.hstack([np.ones((n, 1)), x.astype(np.float32).astype(np.float64)])
+    yn = (y - y.mean()) / y.std()
+    ref = np.linalg.solve(zf.T @ zf + lam ** 2 * np.eye(d + 1), zf.T @ yn)
+    assert rel(w, ref) < 1e-8
+    xt, grad = kern.gradient_x(x[:4])
+    assert tuple(grad.shape) == (4, 0, 0) and xt.shape[1] == d + 1

@@ -353,6 +353,49 @@ class ConvSORFKernel(KernelBase):
         return xtrans
 
 
+class LinearKernel:
+    """kernels/basic_kernels/linear.py: Bayesian linear regression -- the "features" are the input itself
+    (rounded to float32 by the private copy of kernel_baseclass.py:274-288, widened to float64), with a
+    leading column of ones for the intercept.  No random features, no operator of the library; here so that
+    every kernel name of the reference's registry (kernels/__init__.py:21-33) resolves."""
+    supports_fused = False
+    kernel_choice = "Linear"
+
+    def __init__(self, xdim, num_rffs=None, random_seed=123, device="cuda", kernel_spec_parms=None):
+        kernel_spec_parms = kernel_spec_parms or {}
+        if len(xdim) > 2:
+            raise ValueError("The Linear kernel is only applicable for fixed vector input.")
+        self.fit_intercept = kernel_spec_parms.get("intercept", True) is not False
+        self.num_rffs = xdim[1] + (1 if self.fit_intercept else 0)
+        self._xdim, self.device, self.random_seed = tuple(xdim), device, random_seed
+        self.kernel_spec_parms = dict(kernel_spec_parms)
+        self.hyperparams = np.ones((1))
+
+    get_hyperparams = KernelBase.get_hyperparams
+    set_hyperparams = KernelBase.set_hyperparams
+    get_lambda = KernelBase.get_lambda
+    get_num_rffs = KernelBase.get_num_rffs
+    transform_x_y = KernelBase.transform_x_y
+    gradient_x_y = KernelBase.gradient_x_y
+    _as_device_f32 = KernelBase._as_device_f32
+
+    def fused_ok(self):
+        return False
+
+    def transform_x(self, input_x, sequence_length=None):
+        xin = self._as_device_f32(input_x).to(torch.float32)
+        if not self.fit_intercept:
+            return xin.to(torch.float64)
+        xtrans = torch.zeros((xin.shape[0], xin.shape[1] + 1), dtype=torch.float64, device=self.device)
+        xtrans[:, 1:] = xin
+        xtrans[:, 0] = 1.
+        return xtrans
+
+    def gradient_x(self, input_x, sequence_length=None):
+        xtrans = self.transform_x(input_x)
+        return xtrans, torch.zeros((xtrans.shape[0], 0, 0), dtype=torch.float64, device=self.device)
+
+
 class Conv1dTwoLayerKernel(KernelBase):
     """kernels/convolution_kernels/l2_conv1d.py:16-222: a convolution layer with global max-pooling
     (hipConv1dMaxpool: ``init_rffs`` ReLU'd random convolution filters per sequence) whose output feeds an RBF
@@ -573,8 +616,10 @@ def make_kernel(kernel_choice, xdim, num_rffs, random_seed=123, device="cuda", k
         return MiniARDKernel(xdim, num_rffs, random_seed, device, False, kernel_spec_parms)
     if kernel_choice == "Conv1dTwoLayer":
         return Conv1dTwoLayerKernel(xdim, num_rffs, random_seed, device, kernel_spec_parms)
+    if kernel_choice == "Linear":
+        return LinearKernel(xdim, num_rffs, random_seed, device, kernel_spec_parms)
     raise RuntimeError(f"kernel '{kernel_choice}' is outside the hot path this package implements "
-                       f"(supported: {_FIXED + _CONV + ('MiniARD', 'Conv1dTwoLayer')})")
+                       f"(supported: {_FIXED + _CONV + ('MiniARD', 'Conv1dTwoLayer', 'Linear')})")
 
 
 class SRHTCompressor:
