@@ -173,3 +173,20 @@ def test_nmll_gradient_matches_finite_difference_of_exact_nmll():
         flo = nmll.exact_nmll(kern, ds)
         fd[i] = (fhi - flo) / (2 * eps)
     assert np.allclose(grad, fd, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("method,max_iter", [("Nelder-Mead", 100), ("Powell", 100), ("L-BFGS-B", 100)])
+def test_tuning_reaches_the_reference_bar(method, max_iter):
+    """tune_hyperparams (reference xgp_regression.py:564-727) on the reference fixture with the settings of its
+    tests/tuning_tests/test_tuning.py:18-40 (RBF, 512 RFFs, start at (0, 0), exact NMLL): best score < 430."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.tuning import tune_hyperparams
+    g8 = load_golden("g8_e2e.npz")
+    x, y = g8["xtrain"], g8["ytrain"]
+    ds = build_regression_dataset(x, y, chunk_size=2000, device=DEV)
+    kern = make_kernel("RBF", x.shape, 512, 123, DEV, {"intercept": True})
+    hp, nfev, best = tune_hyperparams(kern, ds, tuning_method=method, n_restarts=1,
+                                      starting_hyperparams=np.array([0., 0.]), max_iter=max_iter, nmll_method="exact")
+    assert best < 430
+    assert np.allclose(kern.get_hyperparams(), hp)
