@@ -1,0 +1,74 @@
+"""The model classes (xgpr_amd.models: the reference's user API over this package's functions) driven the way
+the reference's own tests drive its models, against values the reference produced."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_regression_model_follows_the_reference_fit_test():
+    """tests/fitting_tests/test_cg_fit.py:26-40: RBF, 4096 RFFs, rank-256 srht preconditioner, tol 1e-6 ->
+    fewer than 10 iterations; weights / predictions as the reference's (g8); exact mode and variances (g9)."""
+    from xgpr_amd.models import xGPRegression
+    from xgpr_amd.dataset import build_regression_dataset
+    g8, g9 = load_golden("g8_e2e.npz"), load_golden("g9_exact.npz")
+    ds = build_regression_dataset(g8["xtrain"], g8["ytrain"], chunk_size=2000, device=DEV)
+    mod = xGPRegression(num_rffs=4096, kernel_choice="RBF", variance_rffs=12, random_seed=123, device=DEV,
+                        kernel_settings={"intercept": True}, verbose=False)
+    mod.set_hyperparams(g8["hparam_log"], ds)
+    pre, ratio = mod.build_preconditioner(ds, max_rank=256, method="srht")
+    assert np.isclose(ratio, float(g8["ratio"]), rtol=1e-4)
+    niter, losses = mod.fit(ds, preconditioner=pre, max_iter=500, run_diagnostics=True, tol=1e-6, mode="cg")
+    assert niter == int(g8["niter"]) and niter < 10
+    assert np.allclose(mod.predict(g8["xtest"]), g8["preds"], rtol=1e-5, atol=1e-6)
+    # no preconditioner given: the rank is selected automatically, as in the reference's second fit test (:57-73)
+    niter2, _ = mod.fit(ds, max_iter=500, run_diagnostics=True, tol=1e-6, mode="cg", suppress_var=True)
+    assert niter2 < 10
+    # exact mode + variance (g9 settings: 512 RFFs)
+    mod2 = xGPRegression(num_rffs=512, kernel_choice="RBF", variance_rffs=12, random_seed=123, device=DEV,
+                         kernel_settings={"intercept": True}, verbose=False)
+    mod2.set_hyperparams(g9["hparam_log"], ds)
+    mod2.fit(ds, mode="exact")
+    preds, var = mod2.predict(g9["xtest"], get_var=True)
+    assert np.allclose(preds, g9["preds"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(var, g9["pred_var"], rtol=1e-4, atol=1e-9)
+    with pytest.raises(RuntimeError):
+        xGPRegression(num_rffs=64, device=DEV, verbose=False).predict(g9["xtest"])
+
+
+def test_regression_model_nmll_and_tuning_entry_points():
+    from xgpr_amd.models import xGPRegression
+    from xgpr_amd.dataset import build_regression_dataset
+    g8, g10 = load_golden("g8_e2e.npz"), load_golden("g10_nmll.npz")
+    ds = build_regression_dataset(g8["xtrain"], g8["ytrain"], chunk_size=2000, device=DEV)
+    mod = xGPRegression(num_rffs=512, kernel_choice="RBF", variance_rffs=12, random_seed=123, device=DEV,
+                        kernel_settings={"intercept": True}, verbose=False)
+    hp = g10["easy_hparam_log"]
+    assert np.isclose(mod.exact_nmll(hp, ds), float(g10["easy_exact_nmll"]), rtol=1e-6)
+    nll, grad = mod.exact_nmll_gradient(hp, ds)
+    assert np.allclose(grad, g10["easy_grad"], rtol=2e-4, atol=1e-4)
+    settings = {"max_rank": 64, "preconditioner_mode": "srht_2", "nsamples": 25, "nmll_iter": 500, "nmll_tol": 1e-6}
+    assert np.isclose(mod.approximate_nmll(hp, ds, settings), float(g10["easy_approx_nmll"]), rtol=1e-6)
+    _, _, best = mod.tune_hyperparams(ds, tuning_method="L-BFGS-B", starting_hyperparams=np.array([0., 0.]),
+                                      max_iter=100, nmll_method="exact")
+    assert best < 430
+
+
+def test_classification_model_follows_the_reference_classifier_test():
+    """tests/fitting_tests/test_cg_fit.py:76-91 on the reference's wine data (g11)."""
+    from xgpr_amd.models import xGPClassification
+    from xgpr_amd.dataset import build_classification_dataset
+    g = load_golden("g11_classifier.npz")
+    ds = build_classification_dataset(g["xtrain"], g["ytrain"], chunk_size=2000, device=DEV)
+    mod = xGPClassification(num_rffs=1024, kernel_choice="RBF", random_seed=123, device=DEV,
+                            kernel_settings={"intercept": True}, verbose=False)
+    mod.set_hyperparams(g["hparam_log"], ds)
+    pre, _ = mod.build_preconditioner(ds, max_rank=256, method="srht")
+    niter, losses = mod.fit(ds, preconditioner=pre, max_iter=500, run_diagnostics=True, tol=1e-2)
+    assert niter == int(g["niter"]) and niter < 10
+    probs = mod.predict(g["xtest"])
+    assert np.allclose(probs, g["probs"], rtol=1e-4, atol=1e-6)
+    assert (probs.argmax(axis=1) == g["ytest"]).mean() > 0.9
