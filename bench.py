@@ -68,12 +68,16 @@ def make_shard(n_local, d, rank, device):
 
 
 def cpu_baseline(args, budget_s):
-    """The reference CPU algorithm (oracle/: C + OpenMP restatement, pinned against the
-    reference) on a bounded sample of the same workload: feature generation + Z^T(Z p) per
-    8192-row chunk, as fitting_toolkit/cg_tools.py:189-191 does."""
+    """The reference CPU path on a bounded sample of the same workload: per 8192-row chunk, feature generation
+    followed by ``Z.T @ (Z @ p)`` in numpy (the host BLAS), as fitting_toolkit/cg_tools.py:189-191 does.  Feature
+    generation runs through the REFERENCE's own compiled arithmetic core when oracle/_ref/libxgpr_ref.so is
+    present (kind "reference": hadamard_transforms.cpp / shared_rfgen_ops.cpp under the row loop and OpenMP team
+    of rbf_ops.cpp:73-100), otherwise through the oracle's C restatement (kind "port"); both are bit-identical."""
     from oracle import oracle as orc
+    kind = "reference" if orc.RefCore.available() else "port"
     orc.build(ref=False)
-    ops = orc.Oracle()
+    threads = orc.Oracle().num_threads()               # the OpenMP default team size both libraries run with
+    ops = orc.RefCore() if kind == "reference" else orc.Oracle()
     rng = np.random.default_rng(5)
     d, m = args.dim, args.rffs
     radem, chi = orc.draw_sorf_params(m, d, 123)
@@ -82,7 +86,6 @@ def cpu_baseline(args, budget_s):
     chunk = 8192
     x = (rng.standard_normal((chunk, d)) / np.sqrt(d)).astype(np.float32)
     z = np.zeros((chunk, m))
-    w = np.zeros(m)
     ops.cpuRBFFeatureGen(x, z, radem, chi, True)       # warm-up (page in, thread pool)
     t_feat = t_mv = 0.0
     done = 0
@@ -92,16 +95,16 @@ def cpu_baseline(args, budget_s):
         ops.cpuRBFFeatureGen(x, z, radem, chi, True)
         z[:, 0] = 1.0
         t1 = time.perf_counter()
-        ops.ztz_matvec(z, p, w)
+        w = z.T @ (z @ p)
         t2 = time.perf_counter()
         t_feat += t1 - t0
         t_mv += t2 - t1
         done += chunk
     return {
         "value": done * m / (t_feat + t_mv), "unit": "random-features/s",
-        "cores": ops.num_threads(), "kind": "port",
+        "cores": threads, "kind": kind,
         "sample": f"{done} rows of the same workload (d={d}, M={m}) in {chunk}-row chunks: "
-                  f"feature-gen {t_feat:.2f} s + Z^T(Zp) {t_mv:.2f} s; scaled linearly in rows",
+                  f"feature-gen {t_feat:.2f} s + numpy Z^T(Zp) {t_mv:.2f} s; scaled linearly in rows",
         "featgen_only_features_per_s": done * m / t_feat,
         "cg_iters_per_sec_extrapolated": 1.0 / ((t_feat + t_mv) * args.rows / done),
         "host_cpus": os.cpu_count(),

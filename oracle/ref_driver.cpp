@@ -40,18 +40,24 @@ static void rbf_fgen(const T *x, double *out, const int8_t *radem, const T *chi,
     if (fit_intercept) norm = std::sqrt(1.0 / (Ff - 0.5));
     else               norm = std::sqrt(1.0 / Ff);
     int reps = (int)((F + P - 1) / P);
-    T *buf = new T[P];
-    for (long i = 0; i < n; i++) {
-        int pos = 0;
-        for (int k = 0; k < reps; k++) {
-            for (int m = 0; m < d; m++) buf[m] = x[i * d + m];
-            for (int m = d; m < P; m++) buf[m] = 0;
-            S::singleVectorSORF<T>(buf, radem, pos, (int)R, P);
-            S::singleVectorRBFPostProcess<T>(buf, chi, out, P, (int)F, (int)i, k, norm);
-            pos += P;
+    // rows are spread over an OpenMP team with one copy buffer per thread, as rbf_ops.cpp:73-100 does;
+    // bench.py times this entry point as the reference CPU path
+    #pragma omp parallel
+    {
+        T *buf = new T[P];
+        #pragma omp for
+        for (long i = 0; i < n; i++) {
+            int pos = 0;
+            for (int k = 0; k < reps; k++) {
+                for (int m = 0; m < d; m++) buf[m] = x[i * d + m];
+                for (int m = d; m < P; m++) buf[m] = 0;
+                S::singleVectorSORF<T>(buf, radem, pos, (int)R, P);
+                S::singleVectorRBFPostProcess<T>(buf, chi, out, P, (int)F, (int)i, k, norm);
+                pos += P;
+            }
         }
+        delete[] buf;
     }
-    delete[] buf;
 }
 
 // rbf_ops.cpp:178-213 (loop body of rbfGrad_)
