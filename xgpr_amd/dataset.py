@@ -94,15 +94,21 @@ class DeviceDataset:
         standardised y chunk.  ``from_cache``: widen rows of the resident float32 feature cache instead of
         regenerating them -- for the convolution kernels, whose features cost K k-mers x SORF per sequence,
         this lets the preconditioner passes and the CG solve share one generation pass."""
-        zc = self.feature_cache(kernel) if from_cache else None
-        row = 0
-        for xin, yin, ldata in self.get_chunked_data():
-            if zc is None:
+        if not from_cache:
+            for xin, yin, ldata in self.get_chunked_data():
                 z = kernel.transform_x(xin, ldata)
-            else:
-                z = kernel.cache_rows_to_features(zc[row:row + xin.shape[0]])
-            row += xin.shape[0]
-            yield (z, yin) if with_y else z
+                yield (z, yin) if with_y else z
+            return
+        # rows of the cache need no per-chunk generation, so they are served in chunks large enough for the dense
+        # accumulations that consume them to run at full rate (sequence datasets use small chunks: 1024 sequences)
+        zc = self.feature_cache(kernel)
+        step = max(self._chunk_size, 8192)
+        yall = None
+        if with_y:
+            yall = self._ydata if self._max_class is not None else self.normalized_y()
+        for lo in range(0, zc.shape[0], step):
+            z = kernel.cache_rows_to_features(zc[lo:lo + step])
+            yield (z, yall[lo:lo + step]) if with_y else z
 
     def feature_cache_bytes(self, kernel):
         return self._xdata.shape[0] * kernel.get_num_rffs() * 4
