@@ -48,3 +48,20 @@ def test_product_does_not_reach_into_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("test oracle", ""), f"{f} mentions the oracle"
+
+
+def test_every_entry_point_is_mapped_in_integration_md():
+    """INTEGRATION.md maps each exported function (by name, or the *_workspace_bytes family by wildcard) to the
+    reference interface it replaces."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "xgpr_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(xgpr_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) > 30
+    for name in names:
+        base = re.sub(r"_f(32|64)$", "", name)
+        if base.endswith("_workspace_bytes"):
+            assert "xgpr_*_workspace_bytes" in doc or base in doc
+        else:
+            assert base in doc, f"{name} is not mentioned in INTEGRATION.md"
