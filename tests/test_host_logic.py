@@ -53,7 +53,14 @@ def test_kernel_argument_errors():
     with pytest.raises(ValueError):
         make_kernel("Conv1dRBF", (1, 10, 3), 32, device="cpu")
     with pytest.raises(RuntimeError):
-        make_kernel("Linear", (1, 10), 32, device="cpu")
+        make_kernel("Polynomial", (1, 10), 32, device="cpu")        # not a kernel of the reference's registry
+    with pytest.raises(ValueError):
+        make_kernel("MiniARD", (1, 10), 32, device="cpu")           # split_points missing
+    with pytest.raises(ValueError):
+        make_kernel("Conv1dTwoLayer", (1, 10, 3), 32, device="cpu", kernel_spec_parms={"conv_width": 3})
+    lin = make_kernel("Linear", (1, 10), 32, device="cpu")
+    assert lin.get_num_rffs() == 11 and make_kernel("Linear", (1, 10), 32, device="cpu",
+                                                    kernel_spec_parms={"intercept": False}).get_num_rffs() == 10
 
 
 def test_scale_input_matches_numpy_inplace():
