@@ -558,6 +558,28 @@ def g14_two_layer(xgpr):
          conv_width=np.int64(5), init_rffs=np.int64(96), num_rffs=np.int64(128))
 
 
+def g15_crude_tuning(xgpr):
+    """tune_hyperparams_crude on the reference fixture (xgp_regression.py:497-561, lb_optimizer.py, bayes_grid.py):
+    the lambda search at a few fixed sigmas and the result of the whole Bayesian loop."""
+    from xGPR import xGPRegression
+    from xGPR.data_handling.dataset_builder import build_regression_dataset
+    from xGPR.scoring_toolkit.lb_optimizer import shared_hparam_search
+    xtr = np.load(os.path.join(REF_TESTDATA, "0_block_trainxvalues.npy"))
+    ytr = np.load(os.path.join(REF_TESTDATA, "0_block_trainyvalues.npy"))
+    ds = build_regression_dataset(xtr, ytr, chunk_size=2000)
+    mod = xGPRegression(num_rffs=512, kernel_choice="RBF", variance_rffs=12, random_seed=123, device="cpu",
+                        kernel_settings={"intercept": True}, verbose=False)
+    mod.set_hyperparams(np.array([0., 0.]), ds)
+    bounds = mod.kernel.get_bounds()
+    sig, sc, lb = [], [], []
+    for s in (-3.0, -1.0272223, 0.5):
+        score, best_lb = shared_hparam_search(np.array([s]), mod.kernel, ds, bounds[:1, :])
+        sig.append(s), sc.append(score), lb.append(best_lb[0])
+    hp, nfev, best = mod.tune_hyperparams_crude(ds)
+    save("g15_crude_tuning.npz", bounds=bounds, sigmas=np.asarray(sig), scores=np.asarray(sc), best_lbs=np.asarray(lb),
+         crude_hparams=np.asarray(hp), crude_nfev=np.int64(nfev), crude_best=np.float64(best))
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -574,3 +596,4 @@ if __name__ == "__main__":
     g12_mini_ard(xgpr)
     g13_rank_selection(xgpr)
     g14_two_layer(xgpr)
+    g15_crude_tuning(xgpr)

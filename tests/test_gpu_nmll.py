@@ -190,3 +190,28 @@ def test_tuning_reaches_the_reference_bar(method, max_iter):
                                       starting_hyperparams=np.array([0., 0.]), max_iter=max_iter, nmll_method="exact")
     assert best < 430
     assert np.allclose(kern.get_hyperparams(), hp)
+
+
+def test_g15_crude_tuning_vs_reference():
+    """shared_hparam_search (lambda grid from one eigendecomposition of Z^T Z) at fixed sigmas, and the whole
+    tune_hyperparams_crude loop, against the reference's values on its fixture (tests/golden/g15_crude_tuning.npz).
+    Scores are rounded to 3 decimals by the algorithm, grid points are discrete: exact grid agreement is expected."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.crude_tuning import shared_hparam_search, tune_hyperparams_crude
+    from xgpr_amd.tuning import default_bounds
+    g8, g = load_golden("g8_e2e.npz"), load_golden("g15_crude_tuning.npz")
+    ds = build_regression_dataset(g8["xtrain"], g8["ytrain"], chunk_size=2000, device=DEV)
+    kern = make_kernel("RBF", g8["xtrain"].shape, 512, 123, DEV, {"intercept": True})
+    bounds = default_bounds(kern)
+    assert np.allclose(bounds, g["bounds"])
+    for s, score, lb in zip(g["sigmas"], g["scores"], g["best_lbs"]):
+        got_score, got_lb = shared_hparam_search(np.array([s]), kern, ds, bounds[:1, :])
+        assert abs(got_score - float(score)) <= 2e-3
+        assert np.isclose(got_lb[0], float(lb), atol=1e-6)
+    hp, nfev, best = tune_hyperparams_crude(kern, ds)
+    assert abs(best - float(g["crude_best"])) < 0.5 and best < 430
+    assert np.allclose(kern.get_hyperparams(), hp)
+    # the acquisitions themselves may differ (a score that differs in the third decimal changes the surrogate);
+    # the optimum found must be as good and in the same place
+    assert np.abs(hp - g["crude_hparams"]).max() < 0.2

@@ -19,6 +19,7 @@ from .classification import fit_classifier, predict_proba
 from .exact import calc_weights_exact, calc_variance_exact
 from .kernels import make_kernel
 from .preconditioner import RandNysPreconditioner, autoselect_preconditioner
+from .crude_tuning import tune_hyperparams_crude as _tune_crude
 from .tuning import tune_hyperparams as _tune
 
 MAX_VARIANCE_RFFS = 4096            # constants.py:2
@@ -150,6 +151,13 @@ class xGPRegression(_ModelBase):
         self.weights = self.var = None
         return _tune(self.kernel, dataset, bounds, max_iter, tuning_method, starting_hyperparams, tol, n_restarts,
                      nmll_method, manual_settings, self.random_seed, self.verbose)
+
+
+    def tune_hyperparams_crude(self, dataset, bounds=None, random_seed=123, max_bayes_iter=30, subsample=1):
+        """xgp_regression.py:497-561."""
+        self._initialize_kernel(dataset)
+        self.weights = self.var = None
+        return _tune_crude(self.kernel, dataset, bounds, random_seed, max_bayes_iter, subsample, self.verbose)
 
 
 class xGPClassification(_ModelBase):
