@@ -580,6 +580,20 @@ def g15_crude_tuning(xgpr):
          crude_hparams=np.asarray(hp), crude_nfev=np.int64(nfev), crude_best=np.float64(best))
 
 
+def g16_aux(xgpr):
+    """KernelFGen and FastConv1d (kernel_fgen.py, static_layers/fast_conv.py): feature arrays from the reference's
+    classes for small inputs."""
+    from xGPR import KernelFGen, FastConv1d
+    rng = np.random.default_rng(123)
+    x2 = rng.uniform(-1, 1, size=(7, 19))
+    fg = KernelFGen(num_rffs=64, hyperparams=np.array([np.log(0.6)]), num_features=19, kernel_choice="Matern",
+                    device="cpu", kernel_settings={"matern_nu": 1.5}, random_seed=123, verbose=False)
+    x3 = rng.uniform(-1, 1, size=(5, 30, 4))
+    sl = np.array([30, 9, 12, 30, 21], dtype=np.int32)
+    fc = FastConv1d(seq_width=4, device="cpu", random_seed=123, conv_width=9, num_features=70)
+    save("g16_aux.npz", x2=x2, fgen=fg.predict(x2), x3=x3, seqlen=sl, fastconv=fc.predict(x3, sl))
+
+
 if __name__ == "__main__":
     g1_fht()
     g2_rbf()
@@ -597,3 +611,4 @@ if __name__ == "__main__":
     g13_rank_selection(xgpr)
     g14_two_layer(xgpr)
     g15_crude_tuning(xgpr)
+    g16_aux(xgpr)

@@ -72,3 +72,16 @@ def test_classification_model_follows_the_reference_classifier_test():
     probs = mod.predict(g["xtest"])
     assert np.allclose(probs, g["probs"], rtol=1e-4, atol=1e-6)
     assert (probs.argmax(axis=1) == g["ytest"]).mean() > 0.9
+
+
+def test_kernel_fgen_and_fastconv_vs_reference():
+    """KernelFGen / FastConv1d (reference kernel_fgen.py, static_layers/fast_conv.py) against arrays its classes
+    produced (tests/golden/g16_aux.npz): the max-pool extractor is bit-exact, the features within 4e-7 of scale."""
+    from xgpr_amd.models import KernelFGen, FastConv1d
+    g = load_golden("g16_aux.npz")
+    fg = KernelFGen(num_rffs=64, hyperparams=np.array([np.log(0.6)]), num_features=19, kernel_choice="Matern",
+                    device=DEV, kernel_settings={"matern_nu": 1.5}, random_seed=123, verbose=False)
+    z = fg.predict(g["x2"])
+    assert z.shape == g["fgen"].shape and np.abs(z - g["fgen"]).max() <= 4e-7 * np.sqrt(1.0 / 32)
+    fc = FastConv1d(seq_width=4, device=DEV, random_seed=123, conv_width=9, num_features=70)
+    assert np.array_equal(fc.predict(g["x3"], g["seqlen"]), g["fastconv"])

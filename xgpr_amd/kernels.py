@@ -70,10 +70,15 @@ class KernelBase:
         self.radem_diag = torch.from_numpy(np.ascontiguousarray(radem)).to(self.device)
         self.chi_arr = torch.from_numpy(np.ascontiguousarray(chi_arr)).to(self.device)
 
-    def _as_device_f32(self, input_x):
+    def _as_device(self, input_x):
         if isinstance(input_x, np.ndarray):
             input_x = torch.from_numpy(np.ascontiguousarray(input_x))
         return input_x.to(self.device)
+
+    def _as_device_f32(self, input_x):
+        """the private float32 copy every transform starts from (kernel_baseclass.py:274-288): float64 inputs
+        are rounded to float32 BEFORE sigma is applied, as the reference does"""
+        return self._as_device(input_x).to(torch.float32)
 
     def transform_x(self, input_x, sequence_length=None):
         """kernel_baseclass.py:269-299: private float32 copy -> kernel_specific_transform ->
@@ -377,6 +382,7 @@ class LinearKernel:
     get_num_rffs = KernelBase.get_num_rffs
     transform_x_y = KernelBase.transform_x_y
     gradient_x_y = KernelBase.gradient_x_y
+    _as_device = KernelBase._as_device
     _as_device_f32 = KernelBase._as_device_f32
 
     def fused_ok(self):
@@ -556,7 +562,7 @@ class MiniARDKernel(KernelBase):
     def transform_x(self, input_x, sequence_length=None):
         """kernel_baseclass.py:269-299 with mini_ard.py:171-194 (no sigma pre-multiplication: the
         per-feature weights carry the lengthscales)."""
-        xin = self._typed(self._as_device_f32(input_x))             # the private typed copy (:274-288)
+        xin = self._typed(self._as_device(input_x))                 # the private typed copy (:274-288)
         xtrans = self._typed(xin.to(torch.float64) * self.full_ard_weights[None, :])
         output_x = torch.zeros((xtrans.shape[0], self.num_rffs), dtype=torch.float64, device=self.device)
         ext.hipRBFFeatureGen(xtrans, output_x, self.radem_diag, self._typed(self.chi_arr), self.fit_intercept)
@@ -594,7 +600,7 @@ class MiniARDKernel(KernelBase):
         return xtrans, dz_dsigma
 
     def gradient_x(self, input_x, sequence_length=None):
-        xin = self._typed(self._as_device_f32(input_x))
+        xin = self._typed(self._as_device(input_x))
         xtrans, xgrad = self.kernel_specific_gradient(xin, sequence_length)
         if self.fit_intercept:
             xtrans[:, 0] = 1.

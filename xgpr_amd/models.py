@@ -186,3 +186,66 @@ class xGPClassification(_ModelBase):
             raise RuntimeError("Model has not been fitted yet.")
         return predict_proba(self.kernel, self.weights, self.gamma, self._to_device(input_x), sequence_lengths,
                              chunk_size).cpu().numpy()
+
+
+class KernelFGen:
+    """kernel_fgen.py / auxiliary_baseclass.py:27-92: random features of a chosen kernel for use outside a model
+    (kernel k-means, PCA): no intercept column, kernel-specific hyperparameters supplied by the caller."""
+
+    def __init__(self, num_rffs, hyperparams, num_features, kernel_choice="RBF", device="cuda", kernel_settings=None,
+                 random_seed=123, verbose=True):
+        settings = dict(DEFAULT_KERNEL_SPEC_PARMS if kernel_settings is None else kernel_settings)
+        settings["intercept"] = False
+        three_d = kernel_choice.startswith(("Conv1d", "Graph"))
+        xdim = (1, settings.get("conv_width", 10), num_features) if three_d else (1, num_features)
+        self.kernel = make_kernel(kernel_choice, xdim, num_rffs, random_seed, device, settings)
+        self.device, self.verbose = device, verbose
+        full = self.kernel.get_hyperparams()
+        if full.shape[0] > 1:
+            full[1:] = hyperparams
+        self.kernel.set_hyperparams(full, logspace=True)
+
+    def predict(self, input_x, sequence_lengths=None, chunk_size=2000):
+        """-> numpy [N, num_rffs]"""
+        preds = []
+        for i in range(0, input_x.shape[0], chunk_size):
+            sl = None if sequence_lengths is None else sequence_lengths[i:i + chunk_size]
+            preds.append(self.kernel.transform_x(input_x[i:i + chunk_size], sl))
+        return torch.cat(preds).cpu().numpy()
+
+
+class FastConv1d:
+    """static_layers/fast_conv.py with kernels/convolution_kernels/conv_feature_extractor.py:37-108: the static
+    convolution + global max-pool feature extractor (hipConv1dMaxpool) for sequences."""
+
+    def __init__(self, seq_width, device="cuda", random_seed=123, conv_width=9, num_features=512):
+        from math import ceil
+        from scipy.stats import chi as _chi
+        from .kernels import padded_dims
+        self.seq_width, self.num_features, self.conv_width, self.device = seq_width, num_features, conv_width, device
+        rng = np.random.default_rng(random_seed)
+        pdims = padded_dims(conv_width * seq_width)
+        radem = rng.choice(np.asarray([-1, 1], dtype=np.int8), size=(3, 1, ceil(num_features / pdims) * pdims),
+                           replace=True)
+        chi_arr = _chi.rvs(df=pdims, size=num_features, random_state=random_seed).astype(np.float32)
+        self.radem_diag = torch.from_numpy(np.ascontiguousarray(radem)).to(device)
+        self.chi_arr = torch.from_numpy(chi_arr).to(device)
+
+    def predict(self, x_array, sequence_lengths, chunk_size=2000):
+        """-> numpy float32 [N, num_features]"""
+        from . import xgpr_hip_rfgen_ext as ext
+        if sequence_lengths.shape[0] != x_array.shape[0]:
+            raise RuntimeError("The shape[0] of sequence_lengths must match the shape[0] of x_array.")
+        if x_array.shape[2] != self.seq_width:
+            raise ValueError("Unexpected number of features per timepoint / sequence element on this input.")
+        feats = []
+        for i in range(0, x_array.shape[0], chunk_size):
+            xin = x_array[i:i + chunk_size]
+            xin = torch.from_numpy(np.ascontiguousarray(xin)) if isinstance(xin, np.ndarray) else xin
+            xin = xin.to(self.device, torch.float32).contiguous()
+            out = torch.zeros((xin.shape[0], self.num_features), dtype=torch.float32, device=self.device)
+            ext.hipConv1dMaxpool(xin, out, self.radem_diag, self.chi_arr,
+                                 np.ascontiguousarray(np.asarray(sequence_lengths[i:i + chunk_size]).astype(np.int32)),
+                                 self.conv_width)
+            feats.append(out)
+        return torch.cat(feats).cpu().numpy()
