@@ -193,7 +193,8 @@ int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefac
  * datapoint at 8192 features).  xgpr_zcache_matvec_f32 is then the chunk body of the CG matvec
  * (fitting_toolkit/cg_tools.py:189-191) streamed from that cache at HBM speed:
  * w_out = sum_i z_i (z_i . v), z_i = scale * zc[i] with Z[:,0] = 1 under fit_intercept; float64
- * accumulation, deterministic.  num_freqs <= 8192; workspace as for xgpr_ztz_matvec_f32. */
+ * accumulation, deterministic.  num_freqs <= 16384 (one tile of 1024 frequencies per wave up to 8192,
+ * two per wave beyond); workspace as for xgpr_ztz_matvec_f32. */
 int xgpr_rbf_feature_cache_f32(const float *x, float *zc, const int8_t *radem, const float *chi,
                                long n, long d, long num_rffs, long num_freqs, long radem_shape2,
                                void *workspace, size_t workspace_bytes, void *stream);

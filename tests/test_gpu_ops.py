@@ -275,7 +275,9 @@ def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
 
 @pytest.mark.parametrize("d,rffs,icpt,n", [(32, 512, True, 2000), (20, 64, False, 100), (256, 4096, True, 3000),
                                            (100, 3000, True, 777), (1024, 8192, True, 1500), (512, 16384, False, 300),
-                                           (7, 10, True, 33), (64, 6146, True, 5), (3, 2, False, 1)])
+                                           (7, 10, True, 33), (64, 6146, True, 5), (3, 2, False, 1),
+                                           (512, 32768, True, 300), (256, 20002, False, 77), (64, 16386, True, 40),
+                                           (1024, 32768, False, 3), (128, 24580, True, 1)])
 def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
     """The resident float32 feature cache holds exactly the float32 cos/sin the float64 operator
     widens (bit-for-bit: cache * scale == hipRBFFeatureGen output), and the matvec streamed from it
@@ -301,6 +303,11 @@ def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
     ws = torch.empty(ext.ztz_workspace_bytes(rffs, radem.shape[2]), dtype=torch.uint8, device=DEV)
     ext.hipZCacheMatvec(zc, dev(v), out, icpt, ws)
     assert np.abs(out.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+    zz = zc.double() * scale                    # the same float32 values in a float64 product: 1e-12
+    if icpt:
+        zz[:, 0] = 1.0
+    ref2 = zz.T @ (zz @ dev(v))
+    assert float((out - ref2).abs().max()) <= 1e-12 * float(ref2.abs().max())
     out2 = torch.zeros_like(out)
     ext.hipZCacheMatvec(zc, dev(v), out2, icpt, ws)
     assert torch.equal(out, out2)

@@ -164,9 +164,10 @@ class SORFKernel(KernelBase):
     # it on every CG iteration instead of regenerating it (an option the 288 GB of HBM3E allow;
     # the reference cannot hold Z and regenerates it, cg_tools.py:189-191)
     def cache_ok(self):
-        """k = 1 streaming kernel up to num_freqs = 8192 (a workgroup holds all tiles of a datapoint); beyond
-        that the resident cache is applied through the two block contractions with one column."""
-        return self.fused_ok() and (self.num_freqs <= 8192 or self.block_ok())
+        """k = 1 streaming kernel up to num_freqs = 16384 (a workgroup holds all tiles of a datapoint: one tile
+        per wave up to 8192, two beyond); past that the resident cache is applied through the two block
+        contractions with one column."""
+        return self.fused_ok() and (self.num_freqs <= 16384 or self.block_ok())
 
     def build_feature_cache(self, dataset):
         x_scaled = dataset.scaled_x(self.hyperparams[1])
@@ -175,7 +176,7 @@ class SORFKernel(KernelBase):
         return zc
 
     def ztz_matvec_cached(self, zcache, vec, out, workspace):
-        if self.num_freqs <= 8192:
+        if self.num_freqs <= 16384:
             ext.hipZCacheMatvec(zcache, vec, out, self.fit_intercept, workspace)
             return
         need = block_workspace_bytes(zcache.shape[0], self.num_rffs, 1)
@@ -299,7 +300,7 @@ class ConvSORFKernel(KernelBase):
     # is rounded to float32 once -- entries are sums of float32 cos/sin values, so this adds at most
     # 6e-8 relative per entry -- and streamed from HBM afterwards.
     def cache_ok(self):
-        return self.num_freqs <= 8192
+        return self.num_freqs <= 16384
 
     def build_feature_cache(self, dataset):
         n = dataset.get_local_ndatapoints()
@@ -477,7 +478,7 @@ class Conv1dTwoLayerKernel(KernelBase):
 
     # the resident float32 cache holds complete feature rows, as for the other sequence kernels
     def cache_ok(self):
-        return self.num_freqs <= 8192
+        return self.num_freqs <= 16384
 
     def block_ok(self):
         return self.num_rffs % 4 == 0
