@@ -171,11 +171,18 @@ int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const do
  * float64 [M] on the device; scal is float64 [4] = { r.z, alpha, err, beta }.
  *   step1: w += lam2 * p (w arrives holding the all-reduced Z^T Z p); alpha = (r.z)/(p.w);
  *          x += alpha p; r_next = r - alpha w; err = |r| / init_norm   (cg_tools.py:256-265)
- *   step2: beta = (r_next.z_next)/(r.z); p_next = z_next + beta p     (cg_tools.py:271-274) */
+ *   step2: beta = (r_next.z_next)/(r.z); p_next = z_next + beta p     (cg_tools.py:271-274)
+ * stop_tol = 0: plain steps (the host decides when to stop, cg_tools.py:266-269).  stop_tol > 0: for
+ * iterations queued ahead of the host's check (replayed from a HIP graph) the convergence test of
+ * cg_tools.py:266-269 is applied on the device as well: once the error of the previous iteration is
+ * below stop_tol, this and all later steps leave every vector untouched, so x holds exactly the iterate
+ * the host-checked loop returns.  scal is then float64 [8 + max_iterations], zero-initialised except
+ * scal[2] = +inf: scal[4] = stopped flag, scal[5] = iterations applied, scal[8 + i] = err of iteration i. */
 int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next,
-                      const double *z, double *scal, double lam2, double init_norm, long M, void *stream);
+                      const double *z, double *scal, double lam2, double init_norm, long M,
+                      double stop_tol, void *stream);
 int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *p, double *p_next,
-                      double *scal, long M, void *stream);
+                      double *scal, long M, double stop_tol, void *stream);
 
 /* ---- RandNysPreconditioner.batch_matvec for one right-hand side
  * (src/xGPR/preconditioners/rand_nys_preconditioners.py:66-72):

@@ -356,3 +356,36 @@ def test_linear_kernel_fit_equals_ridge_regression():
     assert rel(w, ref) < 1e-8
     xt, grad = kern.gradient_x(x[:4])
     assert tuple(grad.shape) == (4, 0, 0) and xt.shape[1] == d + 1
+
+
+def test_graph_replayed_iterations_equal_plain_launches():
+    """ConjugateGrad.USE_GRAPHS: the iteration captured as a HIP graph and replayed, with the convergence test
+    applied on the device (hipCGStep1/2 stop_tol) -- same iterate, same losses, same iteration count as the
+    host-checked loop, both when the solve converges and when it runs out of iterations."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import ConjugateGrad, cg_fit_lib_internal
+    rng = np.random.default_rng(11)
+    n, d, m = 3000, 20, 512
+    x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+    y = np.sin(x @ rng.standard_normal(d)) + 0.1 * rng.standard_normal(n)
+    ds = build_regression_dataset(x, y, chunk_size=512, device=DEV)
+    kern = make_kernel("RBF", x.shape, m, 123, DEV, {})
+    kern.set_hyperparams(np.array([0.5, 0.6]), logspace=False)
+    pre = RandNysPreconditioner(kern, ds, 48, False, 123, "srht")
+    try:
+        for tol, maxiter, precond, cache in ((1e-7, 200, pre, False), (1e-7, 200, None, True), (1e-12, 7, pre, False),
+                                             (1e-3, 200, pre, True), (1e-7, 1, pre, False)):
+            import warnings
+            out = []
+            for graphs in (False, True):
+                ConjugateGrad.USE_GRAPHS = graphs
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out.append(cg_fit_lib_internal(kern, ds, tol, maxiter, precond, False, cache_features=cache))
+            (w0, n0, l0), (w1, n1, l1) = out
+            assert n0 == n1 and l0 == l1, (tol, maxiter)
+            assert torch.equal(w0, w1)
+    finally:
+        ConjugateGrad.USE_GRAPHS = False

@@ -164,6 +164,9 @@ class ConjugateGrad:
 
         precond(r[0], z[0])
         p[0].copy_(z[0])
+        if trace is None and self._graph_ok(dataset, kernel):
+            return self._replay_iterations(dataset, kernel, precond, r, z, p, x_k, w, lam2, init_norm, maxiter, tol,
+                                           verbose)
         err_host = torch.zeros(maxiter, dtype=torch.float64).pin_memory()
         events = []
         losses, converged = [], False
@@ -210,6 +213,85 @@ class ConjugateGrad:
             if last_err < tol:
                 converged = True
         return x_k, converged, done, losses
+
+    # ---- launch-bound solves: the iteration as a HIP graph (OFF by default -- measured slower, see below).
+    # One CG iteration is 8-9 dependent kernels; on a small shard they take a few microseconds each and the
+    # iteration costs ~70 us whatever the arithmetic.  Here the iteration (matvec, step 1, preconditioner,
+    # step 2) is captured once per parity of the ping-pong buffers and replayed; the convergence test runs
+    # on the device too (hipCGStep1 stop_tol), so an iteration queued before the host has seen the previous
+    # error cannot move x past the iterate the host-checked loop returns (results are identical,
+    # tests/test_gpu_cg.py).  Measured on MI355X / ROCm 7.2 (tools/bench_small_cg.py, 60 iterations):
+    # N=2000, M=512: 77 us per iteration with plain launches, 86 us replayed; N=20000, M=1024 cached: 74 vs
+    # 92; N=1e5, M=4096: 585 vs 600.  The cost is the dependent-dispatch latency on the device, which a
+    # graph replay does not shorten on this stack, plus the replay call itself -- so plain launches stay
+    # the default and the host never blocks the device anyway (the error is read one iteration behind).
+    GRAPH_MAX_WORK = 1 << 31            # rows x features of the shard below which an iteration is launch-bound
+    USE_GRAPHS = False
+
+    def _graph_ok(self, dataset, kernel):
+        return (self.USE_GRAPHS and self.comm.world_size == 1
+                and dataset.get_local_ndatapoints() * kernel.get_num_rffs() <= self.GRAPH_MAX_WORK)
+
+    def _replay_iterations(self, dataset, kernel, precond, r, z, p, x_k, w, lam2, init_norm, maxiter, tol, verbose):
+        from . import xgpr_hip_rfgen_ext as ext
+        dev = x_k.device
+        scal = torch.zeros(8 + maxiter, dtype=torch.float64, device=dev)
+        scal[2] = float("inf")
+
+        def iteration(cur, nxt):
+            self._ztz(dataset, kernel, p[cur], w)
+            ext.hipCGStep1(w, p[cur], x_k, r[cur], r[nxt], z[cur], scal, lam2, init_norm, tol)
+            precond(r[nxt], z[nxt])
+            ext.hipCGStep2(r[nxt], z[nxt], p[cur], p[nxt], scal, tol)
+
+        # everything lazy (scaled inputs / feature cache, workspaces, kernel attributes) happens in this
+        # un-captured first iteration
+        iteration(0, 1)
+        graphs = {}
+        if maxiter > 1:
+            # capturing records, it does not execute: the two captures leave the state untouched
+            # (capture_begin / capture_end on a side stream rather than the torch.cuda.graph context, whose
+            # garbage collection and cache flush cost more than a short solve)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for cur in (1, 0):
+                    graphs[cur] = torch.cuda.CUDAGraph()
+                    graphs[cur].capture_begin()
+                    iteration(cur, 1 - cur)
+                    graphs[cur].capture_end()
+            torch.cuda.current_stream(dev).wait_stream(side)
+        err_host = torch.zeros(maxiter, dtype=torch.float64).pin_memory()
+        events = []
+
+        def queue_read(i):
+            err_host[i:i + 1].copy_(scal[8 + i:9 + i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            events.append(ev)
+
+        queue_read(0)
+        losses, converged = [], False
+        queued, cur = 1, 1
+        while True:
+            # keep one iteration queued ahead of the error being read (the device stops itself)
+            if queued < maxiter and queued <= len(losses) + 1:
+                graphs[cur].replay()
+                queue_read(queued)
+                queued += 1
+                cur = 1 - cur
+                continue
+            i = len(losses)
+            if i >= queued:
+                break
+            events[i].synchronize()
+            losses.append(float(err_host[i]))
+            if verbose and i % 5 == 0 and self.comm.rank == 0:
+                print(f"{i} iterations complete.")
+            if losses[-1] < tol:
+                converged = True
+                break
+        return x_k, converged, len(losses), losses
 
     def fit(self, dataset, kernel, preconditioner, resid, maxiter=200, tol=1e-4, verbose=True,
             nmll_settings=False, trace=None):

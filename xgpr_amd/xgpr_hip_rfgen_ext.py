@@ -275,24 +275,26 @@ def hipZtY(inputArr, radem, chiArr, yvec, outVec, fitIntercept, workspace=None):
         C.c_size_t(workspace.numel()), _stream()))
 
 
-def hipCGStep1(w, p, x, r, r_next, z, scal, lam2, init_norm):
-    """cg_tools.py:256-265 for one right-hand side (see include/xgpr_hip.h)."""
+def hipCGStep1(w, p, x, r, r_next, z, scal, lam2, init_norm, stop_tol=0.0):
+    """cg_tools.py:256-265 for one right-hand side (see include/xgpr_hip.h).  ``stop_tol`` > 0: the
+    convergence test is applied on the device too (iterations queued ahead of the host's check);
+    scal then has 8 + max_iterations entries."""
     for name, t in (("w", w), ("p", p), ("x", x), ("r", r), ("r_next", r_next), ("z", z)):
         _dev(t, name, torch.float64, 1)
     _dev(scal, "scal", torch.float64, 1)
     return _lib.check(_LIB.xgpr_cg_step1_f64(
         C.c_void_p(w.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(r.data_ptr()),
         C.c_void_p(r_next.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(scal.data_ptr()), float(lam2),
-        float(init_norm), w.shape[0], _stream()))
+        float(init_norm), w.shape[0], float(stop_tol), _stream()))
 
 
-def hipCGStep2(r_next, z_next, p, p_next, scal):
+def hipCGStep2(r_next, z_next, p, p_next, scal, stop_tol=0.0):
     """cg_tools.py:271-274 for one right-hand side."""
     for name, t in (("r_next", r_next), ("z_next", z_next), ("p", p), ("p_next", p_next)):
         _dev(t, name, torch.float64, 1)
     return _lib.check(_LIB.xgpr_cg_step2_f64(
         C.c_void_p(r_next.data_ptr()), C.c_void_p(z_next.data_ptr()), C.c_void_p(p.data_ptr()),
-        C.c_void_p(p_next.data_ptr()), C.c_void_p(scal.data_ptr()), r_next.shape[0], _stream()))
+        C.c_void_p(p_next.data_ptr()), C.c_void_p(scal.data_ptr()), r_next.shape[0], float(stop_tol), _stream()))
 
 
 def hipPrecondApply(u_mat, inv_eig, prefactor, rvec, zvec, workspace=None):
