@@ -298,6 +298,24 @@ def main():
                 traffic = pm["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        # the resource this kernel is actually bound by: vector-instruction issue.  Instructions per wave tile
+        # (1024 frequencies of one datapoint) from the SQ counters of this kernel (profiles/r1_fused_pmc_sq.json,
+        # cfg3 shape) x the tiles of this launch / the live kernel time, against one VALU issue per SIMD every 4
+        # cycles at the 2.4 GHz peak clock
+        vector_pipe = None
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_fused_pmc_sq.json")))["wave_ztz_kernel"]["derived"]
+            if (d, m) == (1024, 8192):
+                tiles = n_local * ((m // 2 + 1023) // 1024)
+                peak_inst = 256 * 4 * 2.4e9 / 4
+                inst_s = sq["valu_insts_per_tile"] * tiles / (kern_ms * 1e-3)
+                vector_pipe = {"valu_insts_per_tile": sq["valu_insts_per_tile"], "tiles_per_launch": tiles,
+                               "achieved": inst_s / 1e9, "peak": peak_inst / 1e9, "unit": "G wave-instructions/s",
+                               "frac": inst_s / peak_inst,
+                               "measured_clock_GHz": sq["clock_GHz"],
+                               "valu_busy_at_measured_clock": sq["valu_active_frac_of_simd_cycles"]}
+        except (OSError, KeyError, ValueError):
+            pass
         alg_bytes = 4.0 * d * n_local                   # 4*d bytes per row, X read once
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         fg_bytes = (4.0 * d + 8.0 * m) * fg_rows
@@ -321,6 +339,7 @@ def main():
             "roofline": {"kernel": "wave_ztz_kernel<10, true> (+ pack_radem, reduce_slabs)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
+                         "vector_pipe": vector_pipe,
                          "note": "HBM traffic of this kernel is only the X read; the binding resources are the vector pipe "
                                  "(butterflies + sincos; 64 % busy at 2 waves/SIMD) and LDS-exchange latency: "
                                  "profiles/r1_fused_pmc_sq.json, DESIGN.md section 3"},
