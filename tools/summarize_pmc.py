@@ -15,7 +15,7 @@ def one(pattern):
     f = glob.glob(os.path.join(G, pattern))
     if not f:
         sys.exit(f"missing {pattern}")
-    return f[0]
+    return max(f, key=os.path.getmtime)      # gpurun merges every call's files into gpurun_out/: take the latest
 
 
 shutil.copy(one("prof_stats/*/*kernel_stats.csv"), os.path.join(P, f"{ROUND}_bench_n1_kernel_stats.csv"))
