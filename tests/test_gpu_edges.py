@@ -57,6 +57,27 @@ def test_large_arguments_take_the_double_reduction(oracle):
     assert np.abs(w.cpu().numpy() - wref).max() <= 1e-5 * np.abs(wref).max()
 
 
+@pytest.mark.parametrize("amp", [30.0, 1.0e3, 3.0e4])
+def test_mid_range_arguments_on_the_transcendental_unit(oracle, amp):
+    """Arguments across the whole range the fast path serves (|chi * x| from tens to ~2^18): cos/sin come from
+    v_sin_f32 / v_cos_f32 after a two-term reduction in revolutions (max abs error 3.7e-7 against double libm,
+    tools/sincos_probe.hip); against the reference's glibc cosf/sinf on the bit-identical float32 argument the
+    features stay within 5e-7 * scale (north-star bar: 1e-5 relative)."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(int(amp))
+    radem, chi = orc.draw_sorf_params(4096, 512, 5)
+    x = (rng.standard_normal((64, 512)) * amp / 16.0).astype(np.float32)
+    ref = np.zeros((64, 4096))
+    oracle.cpuRBFFeatureGen(x.copy(), ref, radem, chi, False)
+    out = torch.zeros((64, 4096), dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(dev(x), out, dev(radem), dev(chi), False)
+    scale = np.sqrt(1.0 / 2048)
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err <= 5e-7 * scale, err / scale
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * scale)
+
+
 @pytest.mark.parametrize("L,C,cw", [(9, 21, 9), (12, 21, 9), (40, 1, 1), (30, 48, 21), (33, 100, 11)])
 def test_conv_ragged_and_single_kmer(oracle, L, C, cw):
     """seqlen == conv_width (one k-mer), mixed lengths, graph kernels (conv_width 1), and windows on both
