@@ -87,6 +87,35 @@ def test_fused_matvec_equals_chunked_path(cfg, rows):
     assert abs(a - b) <= 1e-10 * max(abs(a), abs(b))
 
 
+@pytest.mark.parametrize("cfg,rows", [("cfg3", 131_072), ("cfg5", 70_000)])
+def test_cached_matvec_equals_fused_matvec(cfg, rows):
+    """Z^T(Zv) streamed from the resident float32 cache (one tile per wave at cfg3's 4096 frequencies, two tiles
+    per wave at cfg5's 16384) == the regenerating fused kernel (single pass / two passes) on the same rows: the cache
+    holds exactly the float32 cos/sin the fused kernels compute, so only the float64 summation order differs; and
+    the cached operator is additive over a split of the rows."""
+    from xgpr_amd.kernels import make_kernel, scale_input
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    name, _, d, m, parms = _cfg(cfg)
+    k = make_kernel(name, (rows, d), m, 123, DEV, parms)
+    k.set_hyperparams(np.array([0.1, 0.9]), logspace=False)
+    xs = scale_input(_data(rows, d, 8), k.hyperparams[1])
+    g = torch.Generator(device=DEV)
+    g.manual_seed(4)
+    v = torch.randn(m, generator=g, device=DEV, dtype=torch.float64)
+    ws = torch.empty(k.workspace_bytes(), dtype=torch.uint8, device=DEV)
+    zc = torch.empty((rows, m), dtype=torch.float32, device=DEV)
+    k.fill_feature_cache(xs, zc)
+    w_regen, w_cache = torch.zeros(m, dtype=torch.float64, device=DEV), torch.zeros(m, dtype=torch.float64, device=DEV)
+    k.ztz_matvec(xs, v, w_regen, ws)
+    k.ztz_matvec_cached(zc, v, w_cache, ws)
+    assert float((w_cache - w_regen).abs().max() / w_regen.abs().max()) < 1e-12
+    h = rows // 3
+    wa, wb = torch.zeros_like(w_cache), torch.zeros_like(w_cache)
+    ext.hipZCacheMatvec(zc[:h], v, wa, k.fit_intercept, ws)
+    ext.hipZCacheMatvec(zc[h:], v, wb, k.fit_intercept, ws)
+    assert float((wa + wb - w_cache).abs().max() / w_cache.abs().max()) < 1e-12
+
+
 def test_cfg2_cg_solve_residual():
     """BASELINE configs[1]: RBF, N = 1e5, d = 256, 4096 RFFs, one MI355X, CG fit: the returned weights
     satisfy the normal equations to the CG tolerance."""
