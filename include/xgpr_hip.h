@@ -177,10 +177,12 @@ int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const do
  * cg_tools.py:266-269 is applied on the device as well: once the error of the previous iteration is
  * below stop_tol, this and all later steps leave every vector untouched, so x holds exactly the iterate
  * the host-checked loop returns.  scal is then float64 [8 + max_iterations], zero-initialised except
- * scal[2] = +inf: scal[4] = stopped flag, scal[5] = iterations applied, scal[8 + i] = err of iteration i. */
+ * scal[2] = +inf: scal[4] = stopped flag, scal[5] = iterations applied, scal[8 + i] = err of iteration i.
+ * err_out (may be NULL): a second place for err -- e.g. pinned host memory, which the device writes directly
+ * (followed by a system-scope fence), so that the host's lagging read of the error needs no copy command. */
 int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next,
                       const double *z, double *scal, double lam2, double init_norm, long M,
-                      double stop_tol, void *stream);
+                      double stop_tol, double *err_out, void *stream);
 int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *p, double *p_next,
                       double *scal, long M, double stop_tol, void *stream);
 

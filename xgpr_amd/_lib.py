@@ -37,7 +37,7 @@ SIGNATURES = {
     "xgpr_conv1d_maxpool_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_ztz_matvec_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_zty_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
-    "xgpr_cg_step1_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _l, _d, _vp],
+    "xgpr_cg_step1_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _l, _d, _vp, _vp],
     "xgpr_cg_step2_f64": [_vp, _vp, _vp, _vp, _vp, _l, _d, _vp],
     "xgpr_precond_apply_f64": [_vp, _vp, _d, _vp, _vp, _l, _l, _vp, _sz, _vp],
     "xgpr_rbf_feature_cache_f32": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _vp, _sz, _vp],

@@ -179,10 +179,11 @@ int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const do
 }
 
 int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next, const double *z,
-                      double *scal, double lam2, double init_norm, long M, double stop_tol, void *stream) {
+                      double *scal, double lam2, double init_norm, long M, double stop_tol, double *err_out,
+                      void *stream) {
     if (M <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
     hipLaunchKernelGGL(cg_step1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, p, x, r, r_next, z, scal, lam2,
-                       init_norm, M, stop_tol);
+                       init_norm, M, stop_tol, err_out);
     HIP_TRY(hipGetLastError(), "cg_step1_kernel launch");
     return 0;
 }

@@ -275,17 +275,26 @@ def hipZtY(inputArr, radem, chiArr, yvec, outVec, fitIntercept, workspace=None):
         C.c_size_t(workspace.numel()), _stream()))
 
 
-def hipCGStep1(w, p, x, r, r_next, z, scal, lam2, init_norm, stop_tol=0.0):
+def _err_ptr(t):
+    if t is None:
+        return 0
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float64 or t.numel() < 1 or not (t.is_cuda or t.is_pinned()):
+        raise TypeError("err_out: expected a float64 tensor on the device or in pinned host memory")
+    return t.data_ptr()
+
+
+def hipCGStep1(w, p, x, r, r_next, z, scal, lam2, init_norm, stop_tol=0.0, err_out=None):
     """cg_tools.py:256-265 for one right-hand side (see include/xgpr_hip.h).  ``stop_tol`` > 0: the
     convergence test is applied on the device too (iterations queued ahead of the host's check);
-    scal then has 8 + max_iterations entries."""
+    scal then has 8 + max_iterations entries.  ``err_out``: a one-element float64 tensor that also receives
+    the error -- on the device, or in pinned host memory (written by the kernel itself, no copy command)."""
     for name, t in (("w", w), ("p", p), ("x", x), ("r", r), ("r_next", r_next), ("z", z)):
         _dev(t, name, torch.float64, 1)
     _dev(scal, "scal", torch.float64, 1)
     return _lib.check(_LIB.xgpr_cg_step1_f64(
         C.c_void_p(w.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(r.data_ptr()),
         C.c_void_p(r_next.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(scal.data_ptr()), float(lam2),
-        float(init_norm), w.shape[0], float(stop_tol), _stream()))
+        float(init_norm), w.shape[0], float(stop_tol), C.c_void_p(_err_ptr(err_out)), _stream()))
 
 
 def hipCGStep2(r_next, z_next, p, p_next, scal, stop_tol=0.0):
