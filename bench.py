@@ -154,10 +154,10 @@ def main():
     # wrap the fused matvec with HIP events on the launch stream (torch's current stream)
     orig = kern.ztz_matvec
 
-    def timed_matvec(xs, vec, out, ws=None):
+    def timed_matvec(xs, vec, out, ws=None, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig(xs, vec, out, ws)
+        orig(xs, vec, out, ws, **kw)
         e1.record()
         timings.append((e0, e1))
     kern.ztz_matvec = timed_matvec

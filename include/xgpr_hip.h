@@ -149,7 +149,10 @@ int xgpr_conv1d_maxpool_f64(const double *x, float *out, const int8_t *radem, co
  * Deterministic: per-workgroup partial sums are combined in a fixed order.
  * Supported: padded width P = 2^ceil(log2(max(d,2))) <= 1024, num_freqs <= 65536 (one pass
  * over the datapoints up to num_freqs = 8192; beyond that a dot pass and an update pass per
- * window of 65536 datapoints, i.e. the features are generated twice). */
+ * window of 65536 datapoints, i.e. the features are generated twice).
+ * The call packs radem into sign masks at the head of the workspace first; radem == NULL says the
+ * workspace still holds the masks of an earlier call with the same radem (a CG solve calls this once per
+ * iteration with one workspace), and the packing launch is skipped. */
 size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2);
 int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v,
                         double *w_out, long n, long d, long num_rffs, long num_freqs,

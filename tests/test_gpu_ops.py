@@ -267,6 +267,12 @@ def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     out2 = torch.zeros_like(out)
     ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), dev(v), out2, icpt)
     assert torch.equal(out, out2)
+    # a caller-held workspace keeps the packed sign masks: later calls may skip the packing launch
+    ws = torch.empty(ext.ztz_workspace_bytes(rffs, radem.shape[2]), dtype=torch.uint8, device=DEV)
+    out3, out4 = torch.zeros_like(out), torch.zeros_like(out)
+    ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), dev(v), out3, icpt, ws)
+    ext.hipZtZMatvec(dev(x), dev(radem), dev(chi), dev(v), out4, icpt, ws, masksPacked=True)
+    assert torch.equal(out, out3) and torch.equal(out, out4)
     zty = torch.zeros(rffs, dtype=torch.float64, device=DEV)
     ext.hipZtY(dev(x), dev(radem), dev(chi), dev(y), zty, icpt)
     refy = z.T @ y

@@ -51,6 +51,7 @@ class ConjugateGrad:
         self.comm = comm
         self.cache_features = cache_features
         self._ws = None
+        self._ws_masks_of = None     # the radem tensor whose sign masks the workspace holds
         self._bws = None
         self._zwin = None
 
@@ -65,6 +66,7 @@ class ConjugateGrad:
             xs = dataset.scaled_x(kernel.hyperparams[1])
             if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != xs.device:
                 self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=xs.device)
+                self._ws_masks_of = None
             self._matvec_cols(kernel, xs, vec, matvec)
         elif self.BLOCK_KERNELS and vec.is_cuda and hasattr(kernel, "block_ok") and kernel.block_ok():
             self._matvec_block(dataset, kernel, vec, matvec)
@@ -125,10 +127,18 @@ class ConjugateGrad:
         all-reduce); lambda^2 vec is added by the caller."""
         if self._ws is None or self._ws.numel() < kernel.workspace_bytes() or self._ws.device != out.device:
             self._ws = torch.empty(kernel.workspace_bytes(), dtype=torch.uint8, device=out.device)
+            self._ws_masks_of = None
         if self._use_cache(kernel):
             kernel.ztz_matvec_cached(dataset.feature_cache(kernel), vec, out, self._ws)
         else:
-            kernel.ztz_matvec(dataset.scaled_x(kernel.hyperparams[1]), vec, out, self._ws)
+            # the Rademacher sign masks are packed into the workspace by the first call only
+            radem = getattr(kernel, "radem_diag", None)
+            if radem is None:
+                kernel.ztz_matvec(dataset.scaled_x(kernel.hyperparams[1]), vec, out, self._ws)
+            else:
+                kernel.ztz_matvec(dataset.scaled_x(kernel.hyperparams[1]), vec, out, self._ws,
+                                  masks_packed=self._ws_masks_of is radem)
+                self._ws_masks_of = radem
         self.comm.all_reduce_(out)
 
     def _use_cache(self, kernel):

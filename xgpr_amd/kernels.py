@@ -154,8 +154,8 @@ class SORFKernel(KernelBase):
     # materialised Z: fitting_toolkit/cg_tools.py:189-191, scoring_toolkit/exact_nmll_calcs.py:35-37)
     supports_fused = True
 
-    def ztz_matvec(self, x_scaled, vec, out, workspace=None):
-        ext.hipZtZMatvec(x_scaled, self.radem_diag, self.chi_arr, vec, out, self.fit_intercept, workspace)
+    def ztz_matvec(self, x_scaled, vec, out, workspace=None, masks_packed=False):
+        ext.hipZtZMatvec(x_scaled, self.radem_diag, self.chi_arr, vec, out, self.fit_intercept, workspace, masks_packed)
 
     def zty(self, x_scaled, y, out, workspace=None):
         ext.hipZtY(x_scaled, self.radem_diag, self.chi_arr, y, out, self.fit_intercept, workspace)

@@ -237,10 +237,11 @@ def hipConv1dMaxpool(inputArr, outputArr, radem, chiArr, seqlengths, convWidth):
         radem.shape[2], host.shape[0], int(convWidth), wp, wn, _stream()))
 
 
-def hipZtZMatvec(inputArr, radem, chiArr, vec, outVec, fitIntercept, workspace=None):
+def hipZtZMatvec(inputArr, radem, chiArr, vec, outVec, fitIntercept, workspace=None, masksPacked=False):
     """Fused ``Z.T @ (Z @ vec)`` over one shard of (sigma-scaled, float32) rows: the chunk
     body of the reference's CG matvec (fitting_toolkit/cg_tools.py:189-191) with
-    ``kernel.transform_x`` fused in.  ``outVec`` [num_rffs] f64 is overwritten."""
+    ``kernel.transform_x`` fused in.  ``outVec`` [num_rffs] f64 is overwritten.  ``masksPacked``:
+    ``workspace`` still holds the sign masks an earlier call packed from the same ``radem``."""
     x = _dev(inputArr, "inputArr", torch.float32, 2)
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", torch.float32, 1)
@@ -251,6 +252,8 @@ def hipZtZMatvec(inputArr, radem, chiArr, vec, outVec, fitIntercept, workspace=N
     need = _LIB.xgpr_ztz_matvec_workspace_bytes(outVec.shape[0], radem.shape[2])
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=inputArr.device)
+    if masksPacked and workspace is not None:
+        r = C.c_void_p(0)
     return _lib.check(_LIB.xgpr_ztz_matvec_f32(
         x, r, c, v, o, inputArr.shape[0], inputArr.shape[1], outVec.shape[0], chiArr.shape[0],
         radem.shape[2], int(bool(fitIntercept)), C.c_void_p(workspace.data_ptr()),
