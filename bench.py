@@ -191,6 +191,15 @@ def main():
     cached = None
     if kern.cache_ok() and ds.feature_cache_bytes(kern) < 0.6 * torch.cuda.get_device_properties(device).total_memory:
         cgc = ConjugateGrad(comm, cache_features=True)
+        # the allocation is timed apart from the generation pass: a fresh 32.8 GB hipMalloc costs 0.5-0.9 s of
+        # page scrubbing in the driver (once per process; the caching allocator hands the block back instantly
+        # afterwards), the generation pass itself milliseconds
+        torch.cuda.synchronize()
+        talloc0 = time.perf_counter()
+        probe = torch.empty((hi - lo, m), dtype=torch.float32, device=device)
+        torch.cuda.synchronize()
+        cache_alloc_s = time.perf_counter() - talloc0
+        del probe
         tcache0 = time.perf_counter()
         zc = ds.feature_cache(kern)
         torch.cuda.synchronize()
@@ -230,7 +239,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         cached = {"ms_per_step": 1e3 * float(tc.item()) / args.steps, "cg_iters_per_sec": args.steps / float(tc.item()),
-                  "cache_bytes_per_gpu": cbytes, "cache_build_s": cache_build_s,
+                  "cache_bytes_per_gpu": cbytes, "cache_build_s": cache_build_s, "cache_alloc_s": cache_alloc_s,
                   "roofline": {"kernel": "zcache_ztz_kernel<true, 2> (+ reduce_slabs)", "bound": "hbm",
                                "achieved": cbytes / (ck_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": cbytes / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ctraffic,
