@@ -350,7 +350,7 @@ def main():
                          "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
                          "vector_pipe": vector_pipe,
                          "note": "HBM traffic of this kernel is only the X read; the binding resources are the vector pipe "
-                                 "(butterflies + sincos; 63 % busy at 2 waves/SIMD) and LDS-exchange latency: "
+                                 "(butterflies + sincos; 65 % busy at 2 waves/SIMD) and LDS-exchange latency: "
                                  "profiles/r1_fused_pmc_sq.json, DESIGN.md section 3"},
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
