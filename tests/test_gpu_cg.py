@@ -58,22 +58,33 @@ def test_g7_cg_iterates(kname, parms):
         if pre is not None:
             assert errs.max() <= 1e-5, (ptag, errs)
         else:
-            # Un-preconditioned CG on this problem passes through a near-breakdown around
-            # iterations 7-9 (two almost dependent search directions): ANY perturbation of Z --
-            # even 3e-8 relative, below the float32 rounding of the features themselves --
-            # moves those two iterates by ~1e-3 while the ones before and after stay at 1e-7
-            # (measured on the CPU oracle, DESIGN.md "Parity").  All other iterates must meet
-            # the 1e-5 bar; the sensitive pair is bounded.
-            assert np.sort(errs)[-3] <= 1e-5 and errs.max() <= 2e-2, (ptag, errs)
+            # Un-preconditioned CG on this problem passes through a near-breakdown (two almost dependent
+            # search directions) that tests/test_cg_sensitivity.py pins on the CPU oracle: iterates outside
+            # the window follow the size of a perturbation of Z, the ones inside move by 1e-4..2e-2 whatever
+            # its size.  The bound is the envelope measured on the oracle at THIS run's feature error.
+            import cg_sensitivity as cs
+            zall = kern.transform_x(x).cpu().numpy()
+            zor, _, _, _ = cs.oracle_problem(g, kname)
+            eps = max(float(np.abs(zall - zor).max() / scale), 3e-8)
+            assert eps <= 4e-7, eps
+            env, count_range = cs.envelope(g, kname, eps, seeds=range(12))
+            print(f"{kname} none: feature error {eps:.1e} -> oracle envelope " + " ".join(f"{e:.1e}" for e in env))
+            outside = [j for j in range(len(errs)) if j not in cs.WINDOW]
+            assert errs[outside].max() <= 1e-5, (ptag, errs)
+            # inside the window the error is 1 / (a near-zero denominator): heavy-tailed, hence the factor on the 12-sample maximum
+            assert np.all(errs <= np.maximum(1e-5, 10.0 * env)), (ptag, errs, env)
         nl = min(len(losses), len(g[f"{kname}_{ptag}_losses"]))
         if pre is None:
-            nl = min(nl, 6)      # before the near-breakdown window
+            nl = min(nl, cs.WINDOW[0])      # before the near-breakdown window
         assert np.allclose(losses[:nl], g[f"{kname}_{ptag}_losses"][:nl], rtol=1e-4)
         # full solve to the reference's tolerance: same iteration count, same weights
         w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-8, 500, pre, False)
-        # the un-preconditioned solve (100+ iterations through the near-breakdown) may end 1-3 iterations
-        # earlier or later depending on float64 summation order; preconditioned counts are exact +-1
-        assert abs(niter - int(g[f"{kname}_{ptag}_niter"])) <= (1 if pre is not None else 3), (ptag, niter)
+        # preconditioned counts are exact +-1; the un-preconditioned solve (100+ iterations through the
+        # near-breakdown) must end inside the range of counts the perturbed oracle solves end in, +-1
+        if pre is not None:
+            assert abs(niter - int(g[f"{kname}_{ptag}_niter"])) <= 1, (ptag, niter)
+        else:
+            assert count_range[0] - 1 <= niter <= count_range[1] + 1, (ptag, niter, count_range)
         assert rel(w, g[f"{kname}_{ptag}_weights"]) < 1e-5
 
 
