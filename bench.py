@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark of the hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps 20 --warmup 3          (N > 1: starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -28,11 +28,10 @@ Besides the contract fields the JSON line carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -53,10 +52,76 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU-baseline budget: whole 8192-row chunks are processed until this much time is spent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-check", action="store_true",
+                    help="rendezvous only: start / join the ranks, count them with an all-reduce, time the per-iteration "
+                         "all-reduce, print the JSON line and exit (no HIP kernels; also runs on CPU over gloo)")
     return ap.parse_args()
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` with N > 1 and no torch.distributed.run environment: start the N ranks here.
+    Runs BEFORE anything touches the GPU (this process never does): a child ``python -m torch.distributed.run``
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port) is started with the same arguments, waited
+    for, and its exit code becomes ours.  Never an exec of a process that has initialised the GPU."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dist_summary(comm, device, m):
+    """What rank 0 reports about the job's communicator: the number of ranks the backend's all-reduce actually
+    summed over, the backend, and the time of the per-iteration exchange (the all-reduce of w: m float64) measured
+    on this device with the other ranks taking part."""
+    import torch
+    import torch.distributed as dist
+    ones = torch.ones(1, dtype=torch.float64, device=device)
+    comm.all_reduce_(ones)
+    out = {"n_ranks_seen": int(round(float(ones.item()))), "world_size": comm.world_size,
+           "backend": dist.get_backend() if comm.world_size > 1 else "none (single rank)"}
+    if comm.world_size > 1:
+        w = torch.zeros(m, dtype=torch.float64, device=device)
+        for _ in range(5):
+            comm.all_reduce_(w)
+        comm.barrier()
+        reps = 50
+        if device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                comm.all_reduce_(w)
+            e1.record()
+            torch.cuda.synchronize()
+            out["allreduce_w_us_back_to_back"] = 1e3 * e0.elapsed_time(e1) / reps
+        else:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                comm.all_reduce_(w)
+            out["allreduce_w_us_back_to_back"] = 1e6 * (time.perf_counter() - t0) / reps
+        out["allreduce_w_bytes"] = 8 * m
+    return out
+
+
+def gather_per_rank(comm, device, values):
+    """values: list of floats of this rank -> list (per rank) of lists, on every rank."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor(values, dtype=torch.float64, device=device)
+    if comm.world_size == 1:
+        return [mine.tolist()]
+    bufs = [torch.zeros_like(mine) for _ in range(comm.world_size)]
+    dist.all_gather(bufs, mine)
+    return [b.tolist() for b in bufs]
+
+
 def make_shard(n_local, d, rank, device):
+    import numpy as np
+    import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(123 + 1000 * rank)
     x = torch.randn((n_local, d), generator=gen, device=device, dtype=torch.float32) / np.sqrt(d)
@@ -73,6 +138,7 @@ def cpu_baseline(args, budget_s):
     generation runs through the REFERENCE's own compiled arithmetic core when oracle/_ref/libxgpr_ref.so is
     present (kind "reference": hadamard_transforms.cpp / shared_rfgen_ops.cpp under the row loop and OpenMP team
     of rbf_ops.cpp:73-100), otherwise through the oracle's C restatement (kind "port"); both are bit-identical."""
+    import numpy as np
     from oracle import oracle as orc
     kind = "reference" if orc.RefCore.available() else "port"
     orc.build(ref=False)
@@ -113,11 +179,35 @@ def cpu_baseline(args, budget_s):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    import numpy as np
+    import torch
+    if args.dist_check:
+        # loaded by path: the package itself needs the built HIP library, this leg needs only the communicator
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("xgpr_amd_dist", os.path.join(ROOT, "xgpr_amd", "dist.py"))
+        xd = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(xd)
+        on_gpu = torch.cuda.is_available()
+        comm = xd.init_from_env(device_type="cuda" if on_gpu else "cpu")
+        device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        if comm.world_size != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={comm.world_size}")
+        info = dist_summary(comm, device, args.rffs)
+        lo, hi = comm.shard_bounds(args.rows)
+        info["shard_rows_per_rank"] = [r[0] for r in gather_per_rank(comm, device, [float(hi - lo)])]
+        if comm.rank == 0:
+            print(json.dumps({"dist_check": True, "n_gpus": args.gpus, **info}))
+        if comm.world_size > 1:
+            torch.distributed.destroy_process_group()
+        return
     from xgpr_amd import dist as xd
     comm = xd.init_from_env(device_type="cuda")
     if comm.world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={comm.world_size}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={comm.world_size}")
     device = torch.device("cuda", torch.cuda.current_device())
+    dist_info = dist_summary(comm, device, args.rffs)
     from xgpr_amd.kernels import make_kernel
     from xgpr_amd.dataset import DeviceDataset, build_regression_dataset
     from xgpr_amd.preconditioner import RandNysPreconditioner
@@ -162,6 +252,23 @@ def main():
         timings.append((e0, e1))
     kern.ztz_matvec = timed_matvec
 
+    # the exchange step of the iteration: torch.distributed's all-reduce of w.  ProcessGroupNCCL runs RCCL on its
+    # own stream and chains it to the compute stream with events on both sides; the pair of events recorded here on
+    # the compute stream brackets exactly that hand-off + the collective, so the time is what an iteration pays.
+    ar_timings = []
+    orig_ar = comm.all_reduce_
+
+    def timed_all_reduce(tensor):
+        if comm.world_size == 1:
+            return tensor
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_ar(tensor)
+        e1.record()
+        ar_timings.append((e0, e1))
+        return tensor
+    comm.all_reduce_ = timed_all_reduce
+
     def run(iters):
         resid = torch.zeros((m, 2, 1), dtype=torch.float64, device=device)
         resid[:, 0, 0] = zty / n
@@ -170,6 +277,7 @@ def main():
     if args.warmup > 0:
         run(args.warmup)
     timings.clear()
+    ar_timings.clear()
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -183,7 +291,10 @@ def main():
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     t = float(elapsed.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in timings]))
+    ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_timings])) if ar_timings else 0.0
     kern.ztz_matvec = orig
+    comm.all_reduce_ = orig_ar
+    per_rank = gather_per_rank(comm, device, [1e3 * (t1 - t0) / args.steps, kern_ms, ar_ms, float(hi - lo)])
 
     # optional mode, reported beside the headline and never part of it: the shard's feature matrix kept
     # resident in HBM as float32 (32 KB per datapoint) and streamed on every CG iteration instead of
@@ -356,6 +467,12 @@ def main():
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},
             "cached_z_mode": cached,
+            "distributed": {**dist_info,
+                            "per_rank": [{"rank": i, "ms_per_step": v[0], "fused_kernel_ms": v[1],
+                                          "allreduce_ms_per_iter": v[2], "rows": int(v[3])} for i, v in enumerate(per_rank)],
+                            "allreduce_note": "torch.distributed all_reduce (RCCL on ProcessGroupNCCL's stream, chained to "
+                                              "the compute stream with events); allreduce_ms_per_iter is measured by HIP "
+                                              "events on the compute stream around the call, inside the timed CG iterations"},
             "final_loss": losses[-1],
             "precond_build_s": precond_build_s,
         }

@@ -72,7 +72,9 @@ class Oracle:
     reference's extension module (cpu_rf_gen/xgpr_cpu_rfgen_cpp_ext.cpp:24-146)."""
 
     def __init__(self):
-        path = os.path.join(_HERE, "liboracle.so")
+        # XGPR_ORACLE_LIB: an alternative build of the same source (the sanitizer job of
+        # tests/test_oracle_sanitizer.py loads oracle/_asan/liboracle_asan.so through it)
+        path = os.environ.get("XGPR_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build(ref=False)
         self.lib = C.CDLL(path)

@@ -34,5 +34,6 @@ out["derived"] = {
 }
 out["_note"] = ("tools/collect_profiles.sh + tools/summarize_sq.py: fused CG matvec at cfg3 shape, 262144 rows; two rocprofv3 "
                 "--pmc passes of tools/pmc_probe.py; SQ_* cycle counters are in units of 4 cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs")
-json.dump({"wave_ztz_kernel": out}, open(os.path.join(P, "r1_fused_pmc_sq.json"), "w"), indent=1)
+OUT = sys.argv[1] if len(sys.argv) > 1 else "r2_fused_pmc_sq.json"      # file name under profiles/
+json.dump({"wave_ztz_kernel": out}, open(os.path.join(P, OUT), "w"), indent=1)
 print(json.dumps(out["derived"], indent=1), out["duration_us_sq1"])

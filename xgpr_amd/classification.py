@@ -13,12 +13,31 @@ The cost function is where the data is touched: per chunk ``pred = Z @ W``, a ro
 evaluations of a fit, otherwise they are regenerated window by window.  The softmax on the [n, classes]
 logits is elementwise torch code.  Partial sums (gradient, loss) are all-reduced over ranks.
 """
-import numpy as np
+import enum
+from dataclasses import dataclass
+
 import torch
 
 from . import xgpr_hip_rfgen_ext as ext
 from .cg import _resolve_cache_mode
 from .kernels import block_workspace_bytes
+
+
+class StepKind(enum.Enum):
+    """Which rule of the line search produced the accepted step."""
+    FULL = "full"                # the first trial step
+    QUADRATIC = "quadratic"      # the minimiser of the interpolating parabola
+    BACKTRACK = "backtrack"      # a halved step that met the sufficient-decrease test
+    BEST_SEEN = "best_seen"      # nothing met it: the lowest loss evaluated on the ray
+
+
+@dataclass
+class _Trial:
+    """An evaluated point on the search ray: step length, weights, gradient, loss."""
+    step: float
+    wvec: torch.Tensor
+    grad: torch.Tensor
+    loss: float
 
 
 class NonlinearCGClassification:
@@ -31,8 +50,8 @@ class NonlinearCGClassification:
         self.preconditioner = preconditioner
         self.n_iter = 0
         self.losses = []
-        self.last_grad = None
-        self.last_search_direction = None
+        self.step_kinds = []
+        self._prev = None            # (gradient, preconditioned gradient) of the previous iteration
         self.cache_features = _resolve_cache_mode(cache_features, kernel, dataset, block=True)
         self._ws = None
         self._zwin = None
@@ -131,82 +150,77 @@ class NonlinearCGClassification:
             print(f"        Func eval loss {total}", flush=True)
         return grad, total
 
+    # ---- the optimiser.  Same arithmetic as nonlinear_cg_toolkit.py:73-226 (the loss sequence of the
+    # reference's own classifier test reproduces, tests/golden/g11_classifier.npz), organised as: a search
+    # direction object, a list of evaluated trial points, and a step-selection rule that names its outcome.
+    def _evaluate(self, origin, direction, step):
+        wvec = origin.wvec + step * direction
+        grad, loss = self.cost_fun_classification(wvec)
+        return _Trial(step, wvec, grad, loss)
+
+    def _search_direction(self, grad):
+        """Preconditioned Polak-Ribiere direction with restart (beta clipped at 0), nonlinear_cg_toolkit.py:131-152.
+        Returns (descent direction d, vector s whose product with d is the slope used by the line search).
+        The correction is beta times the previous PRECONDITIONED GRADIENT, not the previous direction, and
+        without a preconditioner the reference's slope is -|d|^2 rather than g.d (its search direction is the
+        gradient array itself, updated in place, :136/:148) -- both kept, they decide which steps are accepted."""
+        pgrad = grad if self.preconditioner is None else self.preconditioner.batch_matvec(grad)
+        combined = pgrad
+        if self._prev is not None:
+            prev_grad, prev_pgrad = self._prev
+            beta = float((pgrad * (grad - prev_grad)).sum().item()) / float((prev_grad * prev_pgrad).sum().item())
+            combined = pgrad + max(0.0, beta) * prev_pgrad
+        self._prev = (grad.clone(), pgrad.clone())
+        slope_vec = combined if self.preconditioner is None else grad
+        return -combined, slope_vec
+
+    def _line_search(self, origin, direction, slope, first_step, tol):
+        """One accepted point along ``direction`` from ``origin`` -> (trial, StepKind); nonlinear_cg_toolkit.py:154-226.
+        Sufficient decrease: loss(t) < loss(0) + 1e-4 t slope."""
+        def decreases_enough(trial):
+            return trial.loss < origin.loss + 1e-4 * trial.step * slope
+
+        full = self._evaluate(origin, direction, first_step)
+        # late in the fit a full step that still changes the loss is taken without the interpolation step
+        if self.n_iter >= 10 and abs(abs(full.loss - origin.loss) / origin.loss) > tol and decreases_enough(full):
+            return full, StepKind.FULL
+        # minimiser of the parabola through loss(0), slope(0) and loss(first_step)
+        quad_step = -(slope * first_step ** 2) / (2 * (full.loss - origin.loss - slope * first_step))
+        quad = self._evaluate(origin, direction, quad_step)
+        better, kind = (quad, StepKind.QUADRATIC) if quad.loss < full.loss else (full, StepKind.FULL)
+        if decreases_enough(better):
+            return better, kind
+        # halve from the better of the two until the decrease is sufficient; after ten halvings settle for the
+        # lowest loss seen anywhere on the ray, the starting point included
+        seen = [origin, full, quad]
+        for halvings in range(1, 11):
+            trial = self._evaluate(origin, direction, better.step * 0.5 ** halvings)
+            if decreases_enough(trial):
+                return trial, StepKind.BACKTRACK
+            seen.append(trial)
+        return min(seen, key=lambda t: t.loss), StepKind.BEST_SEEN
+
     def fit_model(self, max_iter=500, tol=1e-4):
-        """nonlinear_cg_toolkit.py:72-110."""
+        """nonlinear_cg_toolkit.py:73-110 -> (weights [M, classes], iterations, loss after every step)."""
         wvec = torch.zeros((self.kernel.get_num_rffs(), self.dataset.get_n_classes()), dtype=torch.float64,
                            device=self.kernel.device)
-        self.n_iter = 0
         grad, loss = self.cost_fun_classification(wvec)
-        self.losses = [loss]
-        last_alpha = None
+        point = _Trial(0.0, wvec, grad, loss)
+        self.n_iter, self.losses, self.step_kinds, self._prev = 0, [loss], [], None
         while self.n_iter < max_iter:
-            grad, loss, wvec, _ = self.update_params(grad, wvec, loss, last_alpha, tol)
-            self.losses.append(loss)
-            if np.abs(np.abs(self.losses[-1] - self.losses[-2]) / self.losses[-2]) < tol:
+            direction, slope_vec = self._search_direction(point.grad)
+            slope = float((slope_vec * direction).sum().item())
+            # first trial step: 1 at the start, afterwards the step that would repeat the previous decrease
+            # (the reference takes the loss from before the previous step, nonlinear_cg_toolkit.py:107)
+            first_step = 1 if self.n_iter == 0 else 2 * (point.loss - self.losses[self.n_iter - 1]) / slope
+            point, kind = self._line_search(point, direction, slope, first_step, tol)
+            point = _Trial(0.0, point.wvec, point.grad, point.loss)
+            self.losses.append(point.loss)
+            self.step_kinds.append(kind)
+            if abs(abs(self.losses[-1] - self.losses[-2]) / self.losses[-2]) < tol:
                 break
             self.n_iter += 1
-            last_alpha = self.losses[self.n_iter - 1]
-        return wvec, self.n_iter, self.losses
-
-    def update_params(self, grad, wvec, loss, previous_loss, tol):
-        """nonlinear_cg_toolkit.py:115-226."""
-        if self.preconditioner is not None:
-            search_direction = self.preconditioner.batch_matvec(grad)
-        else:
-            search_direction = grad      # the SAME array, as in the reference (:136): the in-place update
-                                         # below then also changes ``grad`` in the un-preconditioned case
-        if self.last_grad is not None:
-            polak_ribiere = float((search_direction * (grad - self.last_grad)).sum().item())
-            polak_ribiere /= float((self.last_grad * self.last_search_direction).sum().item())
-            polak_ribiere = max(0., polak_ribiere)
-            course_correction = polak_ribiere * self.last_search_direction
-            self.last_grad = grad.clone()
-            self.last_search_direction = search_direction.clone()
-            search_direction += course_correction
-        else:
-            self.last_grad = grad.clone()
-            self.last_search_direction = search_direction.clone()
-        search_direction = -search_direction
-        alpha0_prime = float((grad * search_direction).sum().item())
-        if previous_loss is None:
-            alpha_init = 1
-        else:
-            alpha_init = 2 * (loss - previous_loss) / alpha0_prime
-        new_wvec = wvec + alpha_init * search_direction
-        full_step_grad, full_step_loss = self.cost_fun_classification(new_wvec)
-        if self.n_iter >= 10:
-            if np.abs(np.abs(full_step_loss - loss) / loss) > tol:
-                if full_step_loss < (loss + alpha_init * 1e-4 * alpha0_prime):
-                    return full_step_grad, full_step_loss, new_wvec, alpha_init
-        alpha_quad = -(alpha0_prime * alpha_init ** 2) / (2 * (full_step_loss - loss - alpha0_prime * alpha_init))
-        quad_wvec = wvec + alpha_quad * search_direction
-        quad_grad, quad_loss = self.cost_fun_classification(quad_wvec)
-        if quad_loss < full_step_loss:
-            if quad_loss < (loss + alpha_quad * 1e-4 * alpha0_prime):
-                return quad_grad, quad_loss, quad_wvec, alpha_quad
-        elif full_step_loss < (loss + alpha_init * 1e-4 * alpha0_prime):
-            return full_step_grad, full_step_loss, new_wvec, alpha_init
-        losses = [loss, full_step_loss, quad_loss]
-        grads = [grad, full_step_grad, quad_grad]
-        wvecs = [wvec, new_wvec, quad_wvec]
-        alphas = [0, alpha_init, alpha_quad]
-        alpha_max = alpha_init
-        if quad_loss < full_step_loss:
-            alpha_max = alpha_quad
-        rfactor = 0.5
-        for _ in range(10):
-            alpha = rfactor * alpha_max
-            candidate_wvec = wvec + alpha * search_direction
-            candidate_grad, candidate_loss = self.cost_fun_classification(candidate_wvec)
-            if candidate_loss < (loss + alpha * 1e-4 * alpha0_prime):
-                return candidate_grad, candidate_loss, candidate_wvec, alpha
-            losses.append(candidate_loss)
-            grads.append(candidate_grad)
-            wvecs.append(candidate_wvec)
-            alphas.append(alpha)
-            rfactor *= 0.5
-        best_idx = int(np.argmin(losses))
-        return grads[best_idx], losses[best_idx], wvecs[best_idx], alphas[best_idx]
+        return point.wvec, self.n_iter, self.losses
 
 
 def fit_classifier(kernel, dataset, preconditioner=None, tol=1e-3, max_iter=500, verbose=False,

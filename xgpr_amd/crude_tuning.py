@@ -91,86 +91,92 @@ def shared_hparam_search(sigma_vals, kernel, dataset, init_bounds, n_pts_per_dim
     return np.round(float(best_score), 3), np.round(np.asarray([best_lb]), 7)
 
 
-def _sigma_grid_pts(num_pts_per_sigma, bounds):
-    """bayes_grid.py:166-200."""
-    if bounds.shape[0] == 2:
-        return np.linspace(bounds[1, 0], bounds[1, 1], num_pts_per_sigma)
-    if bounds.shape[0] == 3:
-        s1 = np.linspace(bounds[1, 0], bounds[1, 1], num_pts_per_sigma)
-        s2 = np.linspace(bounds[2, 0], bounds[2, 1], num_pts_per_sigma)
-        s1, s2 = np.meshgrid(s1, s2)
-        return np.array((s1.ravel(), s2.ravel())).T
-    raise RuntimeError("This routine is only applicable for kernels with < 4 hyperparameters.")
+class SigmaSearch:
+    """Exploration of the kernel-specific hyperparameters (one or two of them, log space) on top of the exhaustive
+    lambda search -- the procedure of scoring_toolkit/bayes_grid.py: an initial design, then a scikit-learn
+    Gaussian-process surrogate of score(sigma) refitted after every evaluation and Thompson-sampled for the next
+    point, until a proposal lands within ``tol`` of a point already evaluated.  Same generator calls, surrogate
+    settings and roundings as the reference, so that a run lands on the same points; tests/golden/g15 pins it."""
+    N_CANDIDATES, N_DRAWS = 500, 15
 
+    def __init__(self, kernel, dataset, bounds, random_seed, lambda_search):
+        if not 2 <= bounds.shape[0] <= 3:
+            raise RuntimeError("Bayesian optimization is only allowed for kernels with 2 - 3 hyperparameters.")
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        from sklearn.gaussian_process.kernels import RBF
+        self.kernel, self.dataset, self.seed = kernel, dataset, random_seed
+        self.lambda_bounds, self.sigma_bounds = bounds[:1, :], bounds[1:, :]
+        self.lambda_search = lambda_search          # keyword arguments of shared_hparam_search
+        self.points, self.log_lambdas, self.scores = [], [], []
+        self.score_cap = np.inf                     # largest finite score of the initial design
+        self.surrogate = GaussianProcessRegressor(kernel=RBF(), normalize_y=True, alpha=1e-6,
+                                                  random_state=random_seed, n_restarts_optimizer=4)
 
-def _random_starting_pts(num_sigma_vals, bounds, random_seed=123):
-    """bayes_grid.py:143-163."""
-    rng = np.random.default_rng(random_seed)
-    sigma_grid = np.empty((num_sigma_vals, bounds.shape[0] - 1))
-    for i in range(sigma_grid.shape[1]):
-        sigma_grid[:, i] = rng.uniform(size=num_sigma_vals, low=bounds[i + 1, 0], high=bounds[i + 1, 1])
-    return sigma_grid
+    def initial_design(self, n_pts):
+        """One sigma: an even grid over its bounds; two: uniform draws, one generator stream per coordinate in turn."""
+        lo, hi = self.sigma_bounds[:, 0], self.sigma_bounds[:, 1]
+        if len(lo) == 1:
+            design = np.linspace(lo[0], hi[0], n_pts)[:, None]
+        else:
+            rng = np.random.default_rng(self.seed)
+            design = np.stack([rng.uniform(size=n_pts, low=lo[i], high=hi[i]) for i in range(len(lo))], axis=1)
+        return np.round(design, 7)
 
+    def evaluate(self, sigma_pt):
+        score, log_lambda = shared_hparam_search(sigma_pt, self.kernel, self.dataset, self.lambda_bounds,
+                                                 **self.lambda_search)
+        self.points.append(np.asarray(sigma_pt))
+        self.log_lambdas.append(log_lambda)
+        self.scores.append(min(score, self.score_cap))
 
-def _propose_new_point(sigma_vals, scores, surrogate, bounds, random_seed, num_cand=500):
-    """bayes_grid.py:103-140: refit the surrogate, Thompson-sample 15 draws over 500 candidates."""
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        xvals = np.vstack(sigma_vals)
-        surrogate.fit(xvals, scores)
-    rng = np.random.default_rng(random_seed)
-    candidates = np.round(rng.uniform(low=bounds[:, 0], high=bounds[:, 1], size=(num_cand, bounds.shape[0])), 7)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        y_candidates = surrogate.sample_y(candidates, n_samples=15, random_state=random_seed)
-    best_idx = np.unravel_index(y_candidates.argmin(), y_candidates.shape)
-    best_cand = candidates[best_idx[0], :]
-    min_dist = np.min(np.linalg.norm(best_cand[None, :] - xvals, axis=1))
-    return best_cand, min_dist, surrogate
+    def cap_scores(self):
+        """After the initial design: infinite scores (failed decompositions) become the worst finite one, which
+        also caps every later score."""
+        finite = [s for s in self.scores if s < np.inf]
+        self.score_cap = max(finite)
+        self.scores = [min(s, self.score_cap) for s in self.scores]
+
+    def propose(self, draw_seed):
+        """Thompson sampling: the candidate holding the minimum over N_DRAWS posterior draws -> (point, distance to
+        the nearest evaluated point)."""
+        evaluated = np.vstack(self.points)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.surrogate.fit(evaluated, self.scores)
+            rng = np.random.default_rng(draw_seed)
+            pool = np.round(rng.uniform(low=self.sigma_bounds[:, 0], high=self.sigma_bounds[:, 1],
+                                        size=(self.N_CANDIDATES, self.sigma_bounds.shape[0])), 7)
+            draws = self.surrogate.sample_y(pool, n_samples=self.N_DRAWS, random_state=draw_seed)
+        winner = pool[np.unravel_index(draws.argmin(), draws.shape)[0]]
+        return winner, float(np.linalg.norm(evaluated - winner[None, :], axis=1).min())
+
+    def best(self):
+        i = int(np.argmin(self.scores))
+        return np.concatenate([self.log_lambdas[i], self.points[i]]), self.scores[i]
 
 
 def bayes_grid_tuning(kernel, dataset, bounds, random_seed, max_iter, verbose, tol=1e-1, n_pts_per_dim=100, n_cycles=1,
                       n_init_pts=10, subsample=1):
     """bayes_grid.py:12-100 -> (best hyperparameters (log), (sigma points, scores), best score, iterations)."""
-    from sklearn.gaussian_process import GaussianProcessRegressor as GPR
-    from sklearn.gaussian_process.kernels import RBF
-    if bounds.shape[0] >= 4 or bounds.shape[0] < 2:
-        raise RuntimeError("Bayesian optimization is only allowed for kernels with 2 - 3 hyperparameters.")
-    sigma_grid = _sigma_grid_pts(n_init_pts, bounds) if bounds.shape[0] == 2 \
-        else _random_starting_pts(n_init_pts, bounds, random_seed)
-    sigma_grid = np.round(sigma_grid, 7)
-    if len(sigma_grid.shape) == 1:
-        sigma_grid = sigma_grid.reshape(-1, 1)
-    sigma_grid = list(sigma_grid)
-    lb_vals, scores = [], []
-    for i, sigma_pt in enumerate(sigma_grid):
-        score, lb_val = shared_hparam_search(sigma_pt, kernel, dataset, bounds[:1, :], n_pts_per_dim, n_cycles, subsample)
-        scores.append(score)
-        lb_vals.append(lb_val)
+    search = SigmaSearch(kernel, dataset, bounds, random_seed,
+                         dict(n_pts_per_dim=n_pts_per_dim, n_cycles=n_cycles, subsample=subsample))
+    for sigma_pt in search.initial_design(n_init_pts):
+        search.evaluate(sigma_pt)
         if verbose:
-            print(f"Grid point {i} acquired.")
-    scores = np.asarray(scores)
-    smallest_non_inf_val = np.max(scores[scores < np.inf])
-    scores[scores == np.inf] = smallest_non_inf_val
-    scores = scores.tolist()
-    surrogate = GPR(kernel=RBF(), normalize_y=True, alpha=1e-6, random_state=random_seed, n_restarts_optimizer=4)
-    sigma_bounds = bounds[1:, :]
-    iternum = len(sigma_grid)
-    for iternum in range(len(sigma_grid), max_iter):
-        new_sigma, min_dist, surrogate = _propose_new_point(sigma_grid, scores, surrogate, sigma_bounds,
-                                                            random_seed + iternum)
+            print(f"initial design: {len(search.points)} of {n_init_pts} evaluated")
+    search.cap_scores()
+    n_evals = len(search.points)
+    # draw seeds follow the evaluation count; the final count reported is the index of the last proposal
+    last = n_evals
+    for last in range(n_evals, max_iter):
+        sigma_pt, distance = search.propose(random_seed + last)
         if verbose:
-            print(f"New hparams: {new_sigma}")
-        score, lb_val = shared_hparam_search(new_sigma, kernel, dataset, bounds[:1, :], n_pts_per_dim, n_cycles, subsample)
-        sigma_grid.append(new_sigma)
-        lb_vals.append(lb_val)
-        scores.append(min(score, smallest_non_inf_val))
-        if min_dist < tol:
+            print(f"proposal {last}: sigma {sigma_pt}, distance to nearest evaluated point {distance:.3g}")
+        search.evaluate(sigma_pt)
+        if distance < tol:
             break
-    best_hparams = np.empty((bounds.shape[0]))
-    best_hparams[1:] = sigma_grid[np.argmin(scores)]
-    best_hparams[:1] = lb_vals[np.argmin(scores)]
-    return best_hparams, (sigma_grid, scores), np.min(scores), iternum
+    best_hparams, best_score = search.best()
+    return best_hparams, (search.points, search.scores), best_score, last
 
 
 def tune_hyperparams_crude(kernel, dataset, bounds=None, random_seed=123, max_bayes_iter=30, subsample=1, verbose=False):

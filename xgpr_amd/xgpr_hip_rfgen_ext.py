@@ -7,12 +7,17 @@ in-place semantics, same error behaviour -- arguments are *not* converted (wrong
 device or contiguity raises ``TypeError`` like nanobind's ``.noconvert()``), validation
 failures raise ``RuntimeError`` with the reference's messages, and every function returns 0.
 
-Arrays are ``torch`` tensors on the HIP device (the reference takes cupy arrays; cupy is
-not part of this image).  ``seqlengths`` stays on the HOST (int32 numpy array or CPU
-tensor), as in the reference's CUDA module (gpu_rf_gen/convolution_ops/rbf_convolution.h:19).
-Calls are asynchronous on torch's current stream.
+Arrays are device arrays of any producer that speaks DLPack (``__dlpack__`` / a DLPack capsule; a torch-ROCm
+tensor exports device type kDLROCM) or ``__cuda_array_interface__`` -- what nanobind's
+``nb::ndarray<..., nb::device::cuda>`` accepts in the reference, so its cupy callers
+(kernels/basic_kernels/sorf_kernel_baseclass.py:104-126) can pass their arrays as they are.  They are adopted
+zero-copy (``torch.from_dlpack`` / ``torch.as_tensor``): the in-place operators write the producer's own memory.
+``seqlengths`` stays on the HOST (int32 numpy array or CPU tensor), as in the reference's CUDA module
+(gpu_rf_gen/convolution_ops/rbf_convolution.h:19).  Calls are asynchronous on torch's current stream.
 """
 import ctypes as C
+import functools
+import inspect
 
 import numpy as np
 import torch
@@ -28,9 +33,40 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _adopt(obj, name):
+    """A zero-copy torch view of a device array from any producer; never a conversion (a host array stays a host
+    array and is then refused by _dev, like nanobind's .noconvert())."""
+    if isinstance(obj, torch.Tensor) or obj is None:
+        return obj
+    try:
+        if hasattr(obj, "__dlpack__") or type(obj).__name__ == "PyCapsule":
+            return torch.from_dlpack(obj)
+        if hasattr(obj, "__cuda_array_interface__"):
+            return torch.as_tensor(obj, device="cuda")
+    except (RuntimeError, ValueError, BufferError) as exc:
+        raise TypeError(f"{name}: could not adopt the array through DLPack / __cuda_array_interface__: {exc}") from exc
+    raise TypeError(f"{name}: expected a device array (torch tensor, DLPack or __cuda_array_interface__ producer)")
+
+
+def _array_args(*names):
+    """Decorator: the named arguments may come from any DLPack / __cuda_array_interface__ producer."""
+    def wrap(fn):
+        sig = inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def inner(*args, **kwargs):
+            bound = sig.bind(*args, **kwargs)
+            for nm in names:
+                if nm in bound.arguments:
+                    bound.arguments[nm] = _adopt(bound.arguments[nm], nm)
+            return fn(*bound.args, **bound.kwargs)
+        return inner
+    return wrap
+
+
 def _dev(t, name, dtype, ndim):
     if not isinstance(t, torch.Tensor):
-        raise TypeError(f"{name}: expected a torch tensor on the HIP device")
+        raise TypeError(f"{name}: expected a device array")
     if not t.is_cuda:
         raise TypeError(f"{name}: expected a device tensor, got a host tensor")
     if dtype is not None and t.dtype != dtype:
@@ -74,6 +110,7 @@ def _seqlens(seqlengths, device):
     return host, dev
 
 
+@_array_args("inputArr")
 def hipFastHadamardTransform2D(inputArr):
     """In-place un-normalised FHT over the last axis of a 2-d array
     (cudaFastHadamardTransform2D, xgpr_cuda_rfgen_cpp_ext.cpp:21-24)."""
@@ -82,6 +119,7 @@ def hipFastHadamardTransform2D(inputArr):
     return _lib.check(getattr(_LIB, f"xgpr_fht_{s}")(p, inputArr.shape[0], 1, inputArr.shape[1], _stream()))
 
 
+@_array_args("inputArr")
 def hipFastHadamardTransform(inputArr):
     """3-d form (cpuFastHadamardTransform, cpu_rf_gen/xgpr_cpu_rfgen_cpp_ext.cpp:24-30)."""
     s = _ftype(inputArr, "inputArr")
@@ -90,6 +128,7 @@ def hipFastHadamardTransform(inputArr):
                                                       inputArr.shape[2], _stream()))
 
 
+@_array_args("inputArr", "radem")
 def hipSRHT(inputArr, radem):
     """cudaSRHT (xgpr_cuda_rfgen_cpp_ext.cpp:25-30)."""
     s = _ftype(inputArr, "inputArr")
@@ -106,6 +145,7 @@ def _radem3(radem):
     return r
 
 
+@_array_args("inputArr", "radem", "sampler", "outputArr", "yArr", "ztyOut", "workspace")
 def hipSRHTSample(inputArr, radem, sampler, outputArr, ncols=None, yArr=None, ztyOut=None, workspace=None):
     """``outputArr[:, :ncols] = cudaSRHT(pad(inputArr))[:, sampler[:ncols]]`` without touching inputArr
     (srht_compressor.py:87-97 in one pass).  outputArr may have more than ncols columns (row pitch).
@@ -143,6 +183,7 @@ def srht_sample_ok(padded_width, dtype):
     return padded_width * (8 if dtype == torch.float64 else 4) <= 128 * 1024
 
 
+@_array_args("inputArr", "outputArr", "radem", "chiArr")
 def hipRBFFeatureGen(inputArr, outputArr, radem, chiArr, fitIntercept):
     """cudaRBFFeatureGen (xgpr_cuda_rfgen_cpp_ext.cpp:32-40).  The output is overwritten
     (as by the reference's CUDA kernel, rbf_ops.cu:121-127)."""
@@ -157,6 +198,7 @@ def hipRBFFeatureGen(inputArr, outputArr, radem, chiArr, fitIntercept):
         chiArr.shape[0], radem.shape[2], int(bool(fitIntercept)), wp, wn, _stream()))
 
 
+@_array_args("inputArr", "outputArr", "gradArr", "radem", "chiArr")
 def hipRBFGrad(inputArr, outputArr, gradArr, radem, chiArr, sigma, fitIntercept):
     """cudaRBFGrad (xgpr_cuda_rfgen_cpp_ext.cpp:41-49)."""
     s = _ftype(inputArr, "inputArr")
@@ -174,6 +216,7 @@ def hipRBFGrad(inputArr, outputArr, gradArr, radem, chiArr, sigma, fitIntercept)
         int(bool(fitIntercept)), wp, wn, _stream()))
 
 
+@_array_args("inputArr", "outputArr", "precompWeights", "sigmaMap", "sigmaVals", "gradArr")
 def hipMiniARDGrad(inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gradArr, fitIntercept):
     """cudaMiniARDGrad (xgpr_cuda_rfgen_cpp_ext.cpp:50-60)."""
     s = _ftype(inputArr, "inputArr")
@@ -190,6 +233,7 @@ def hipMiniARDGrad(inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gra
                          int(bool(fitIntercept)), _stream()))
 
 
+@_array_args("inputArr", "outputArr", "radem", "chiArr")
 def hipConv1dFGen(inputArr, outputArr, radem, chiArr, seqlengths, convWidth, scalingType):
     """cudaConv1dFGen (xgpr_cuda_rfgen_cpp_ext.cpp:70-80); results are added into outputArr."""
     s = _ftype(inputArr, "inputArr")
@@ -205,6 +249,7 @@ def hipConv1dFGen(inputArr, outputArr, radem, chiArr, seqlengths, convWidth, sca
         radem.shape[2], host.shape[0], int(convWidth), int(scalingType), wp, wn, _stream()))
 
 
+@_array_args("inputArr", "outputArr", "radem", "chiArr", "gradArr")
 def hipConvGrad(inputArr, outputArr, radem, chiArr, seqlengths, gradArr, sigma, convWidth, scalingType):
     """cudaConvGrad (xgpr_cuda_rfgen_cpp_ext.cpp:81-92)."""
     s = _ftype(inputArr, "inputArr")
@@ -222,6 +267,7 @@ def hipConvGrad(inputArr, outputArr, radem, chiArr, seqlengths, gradArr, sigma, 
         int(scalingType), wp, wn, _stream()))
 
 
+@_array_args("inputArr", "outputArr", "radem", "chiArr")
 def hipConv1dMaxpool(inputArr, outputArr, radem, chiArr, seqlengths, convWidth):
     """cudaConv1dMaxpool (xgpr_cuda_rfgen_cpp_ext.cpp:61-69); float32 output."""
     s = _ftype(inputArr, "inputArr")
@@ -237,6 +283,7 @@ def hipConv1dMaxpool(inputArr, outputArr, radem, chiArr, seqlengths, convWidth):
         radem.shape[2], host.shape[0], int(convWidth), wp, wn, _stream()))
 
 
+@_array_args("inputArr", "radem", "chiArr", "vec", "outVec", "workspace")
 def hipZtZMatvec(inputArr, radem, chiArr, vec, outVec, fitIntercept, workspace=None, masksPacked=False):
     """Fused ``Z.T @ (Z @ vec)`` over one shard of (sigma-scaled, float32) rows: the chunk
     body of the reference's CG matvec (fitting_toolkit/cg_tools.py:189-191) with
@@ -260,6 +307,7 @@ def hipZtZMatvec(inputArr, radem, chiArr, vec, outVec, fitIntercept, workspace=N
         C.c_size_t(workspace.numel()), _stream()))
 
 
+@_array_args("inputArr", "radem", "chiArr", "yvec", "outVec", "workspace")
 def hipZtY(inputArr, radem, chiArr, yvec, outVec, fitIntercept, workspace=None):
     """Fused ``Z.T @ y`` over one shard (scoring_toolkit/exact_nmll_calcs.py:35-37)."""
     x = _dev(inputArr, "inputArr", torch.float32, 2)
