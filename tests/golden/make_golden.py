@@ -594,21 +594,118 @@ def g16_aux(xgpr):
     save("g16_aux.npz", x2=x2, fgen=fg.predict(x2), x3=x3, seqlen=sl, fastconv=fc.predict(x3, sl))
 
 
+# ---------------------------------------------------------------- G17: BASELINE configs[3] shape (cfg4), conv kernel
+def cfg4_inputs(nseq=4):
+    """The cfg4-shaped input both this script and the GPU tests build (kept out of the .npz: it is a seeded draw):
+    one-hot protein-like sequences, L = 512, 21 channels, lengths spanning conv_width .. 512."""
+    rng = np.random.default_rng(123)
+    L, C = 512, 21
+    seqlen = np.array([512, 64, 301, 9, 130, 477][:nseq], dtype=np.int32)
+    x = np.zeros((nseq, L, C), dtype=np.float32)
+    for i in range(nseq):
+        x[i, np.arange(seqlen[i]), rng.integers(0, C, size=seqlen[i])] = 1.0
+        # positions past seqlen hold junk the operator must never read into a k-mer
+        x[i, seqlen[i]:, :] = rng.standard_normal((L - seqlen[i], C)).astype(np.float32)
+    return x, seqlen
+
+
+def g17_cfg4_conv(xgpr):
+    """The reference's Conv1dRBF kernel class at BASELINE configs[3]'s shape -- L = 512, C = 21, conv_width 9
+    (padded window 256), 16384 RFFs = 8 wave tiles, 32 SORF repeats -- through its own transform_x
+    (kernels/convolution_kernels/conv_kernel_baseclass.py:116-147 -> rbf_convolution.cpp:84-136) for the three
+    averaging modes; sequence lengths from one k-mer (9) to the full 504 k-mers."""
+    from xGPR.kernels import KERNEL_NAME_TO_CLASS
+    x, seqlen = cfg4_inputs()
+    hyper = np.array([1.0, 0.8])
+    out = dict(hyperparams=hyper, seqlen=seqlen, num_rffs=np.int64(16384), conv_width=np.int64(9),
+               x_checksum=np.float64(np.abs(x.astype(np.float64)).sum()))
+    for avg in ("none", "sqrt", "full"):
+        kern = KERNEL_NAME_TO_CLASS["Conv1dRBF"](x.shape, 16384, random_seed=123, device="cpu",
+                                                 kernel_spec_parms={"conv_width": 9, "averaging": avg})
+        kern.set_hyperparams(hyper, logspace=False)
+        out[f"z_{avg}"] = kern.transform_x(x.astype(np.float64), seqlen)
+    save("g17_cfg4_conv.npz", **out)
+
+
+# ---------------------------------------------------------------- G18: BASELINE configs[4] shape (cfg5), preconditioner build
+def cfg5_inputs(n=4096, d=512):
+    """Seeded cfg5-shaped inputs (X ~ N(0,1)/sqrt(d), y = sin(Xa) + 0.1 eps), float32-representable."""
+    rng = np.random.default_rng(123)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    a = rng.standard_normal(d) * 3.0
+    y = np.sin(x.astype(np.float64) @ a) + 0.1 * rng.standard_normal(n)
+    return x, y
+
+
+def g18_cfg5_precond(xgpr):
+    """The reference's randomized-Nystrom preconditioner at BASELINE configs[4]'s shape -- d = 512, 32768 RFFs
+    (SRHT width 32768 in float64), rank 2048, methods srht and srht_2 -- on 4096 datapoints: its own
+    SRHTCompressor + single_pass_srht_zty for the accumulated sketch (rand_nys_constructors.py:96-123,
+    srht_compressor.py:87-97), RandNysPreconditioner for eigenvalues / ratio / U (:127-296,
+    rand_nys_preconditioners.py:18-72), and the preconditioned CG solve that follows."""
+    import warnings
+    from xGPR.data_handling.dataset_builder import build_regression_dataset
+    from xGPR.kernels import KERNEL_NAME_TO_CLASS
+    from xGPR.kernels.srht_compressor import SRHTCompressor
+    from xGPR.preconditioners.rand_nys_constructors import single_pass_srht_zty
+    from xGPR.preconditioners.rand_nys_preconditioners import RandNysPreconditioner
+    from xGPR.fitting_toolkit.cg_fitting_toolkit import cg_fit_lib_internal
+    n, d, m, rank = 4096, 512, 32768, 2048
+    x, y = cfg5_inputs(n, d)
+    hyper = np.array([0.1, 1.0])
+    ds = build_regression_dataset(x.astype(np.float64), y, chunk_size=2048)
+    kern = KERNEL_NAME_TO_CLASS["RBF"]((n, d), m, random_seed=123, device="cpu", kernel_spec_parms={})
+    kern.set_hyperparams(hyper, logspace=False)
+    out = dict(hyperparams=hyper, n=np.int64(n), d=np.int64(d), num_rffs=np.int64(m), rank=np.int64(rank),
+               chunk_size=np.int64(2048), x_checksum=np.float64(np.abs(x.astype(np.float64)).sum()),
+               y_checksum=np.float64(np.abs(y).sum()), y_mean=np.float64(ds.get_ymean()), y_std=np.float64(ds.get_ystd()))
+    # the accumulated sketch itself, summarised: Frobenius norm, a fixed probe contraction, sampled entries
+    comp = SRHTCompressor(rank, m, device="cpu", random_seed=123)
+    acc = np.zeros((rank, m))
+    zty = np.zeros(m)
+    yty = single_pass_srht_zty(ds, kern, comp, acc, zty, False)
+    probe_r, probe_c = np.cos(np.arange(rank) * 0.37), np.sin(np.arange(m) * 0.11)
+    ri, ci = (np.arange(64) * 31) % rank, (np.arange(64) * 509) % m
+    out.update(acc_fro=np.float64(np.linalg.norm(acc)), acc_probe=np.float64(probe_r @ acc @ probe_c),
+               acc_left=probe_r @ acc, acc_samples=acc[ri, ci], acc_sample_rows=ri, acc_sample_cols=ci,
+               zty=zty, yty=np.float64(yty), srht_radem=comp.radem, srht_col_sampler=comp.col_sampler)
+    # one SRHT'd + sampled feature row block for the operator-level check (8 rows)
+    z8 = kern.transform_x(x[:8].astype(np.float64))
+    out["z_first8"] = z8
+    out["z8_compressed"] = comp.transform_x(z8)
+    del acc
+    v = np.linspace(-1, 1, m)
+    for ptag, method in (("srht", "srht"), ("srht2", "srht_2")):
+        pre = RandNysPreconditioner(kern, ds, rank, False, 123, method)
+        out[f"{ptag}_eig"] = pre.eig
+        out[f"{ptag}_ratio"] = np.float64(pre.achieved_ratio)
+        out[f"{ptag}_prefactor"] = np.float64(pre.prefactor)
+        out[f"{ptag}_uutv"] = pre.u_mat @ (pre.u_mat.T @ v)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-6, 500, pre, False)
+        out[f"{ptag}_weights"] = w
+        out[f"{ptag}_niter"] = np.int64(niter)
+        out[f"{ptag}_losses"] = np.asarray(losses)
+        print(f"  G18 {ptag}: ratio {pre.achieved_ratio:.4g}, niter {niter}")
+        del pre
+    save("g18_cfg5_precond.npz", **out)
+
+
 if __name__ == "__main__":
-    g1_fht()
-    g2_rbf()
-    g3_conv()
-    g4_maxpool()
-    g5_srht()
-    xgpr = import_reference()
-    g6_draws(xgpr)
-    g7_cg(xgpr)
-    g8_e2e(xgpr)
-    g9_exact(xgpr)
-    g10_nmll(xgpr)
-    g11_classifier(xgpr)
-    g12_mini_ard(xgpr)
-    g13_rank_selection(xgpr)
-    g14_two_layer(xgpr)
-    g15_crude_tuning(xgpr)
-    g16_aux(xgpr)
+    # python make_golden.py            -> everything;   python make_golden.py g17 g18  -> only the named fixtures
+    plain = [g1_fht, g2_rbf, g3_conv, g4_maxpool, g5_srht]
+    with_ref = [g6_draws, g7_cg, g8_e2e, g9_exact, g10_nmll, g11_classifier, g12_mini_ard, g13_rank_selection,
+                g14_two_layer, g15_crude_tuning, g16_aux, g17_cfg4_conv, g18_cfg5_precond]
+    wanted = set(sys.argv[1:])
+
+    def selected(fn):
+        return not wanted or fn.__name__.split("_")[0] in wanted
+    for fn in plain:
+        if selected(fn):
+            fn()
+    if any(selected(fn) for fn in with_ref):
+        xgpr = import_reference()
+        for fn in with_ref:
+            if selected(fn):
+                fn(xgpr)

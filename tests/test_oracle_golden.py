@@ -319,3 +319,48 @@ def test_g14_two_layer_kernel_oracle_vs_reference(oracle):
     assert np.array_equal(k.transform_x(g["x"], g["seqlen"]), g["features"])
     f, gr = k.gradient_x(g["x"], g["seqlen"])
     assert np.array_equal(f, g["grad_features"]) and np.array_equal(gr, g["grad"])
+
+
+def test_g17_cfg4_conv_shape(oracle):
+    """BASELINE configs[3]'s shape (L = 512, C = 21, conv_width 9, 16384 RFFs): the oracle's kernel restatement
+    reproduces the reference's Conv1dRBF.transform_x bit for bit for the three averaging modes."""
+    from test_gpu_cfg_shapes import cfg4_inputs
+    g = load_golden("g17_cfg4_conv.npz")
+    x, seqlen = cfg4_inputs()
+    assert np.isclose(np.abs(x.astype(np.float64)).sum(), float(g["x_checksum"]), rtol=1e-12)
+    for avg in ("none", "sqrt", "full"):
+        k = orc.OracleKernel("Conv1dRBF", int(g["num_rffs"]), x.shape, g["hyperparams"], 123,
+                             conv_width=int(g["conv_width"]), averaging=avg, ops=oracle)
+        assert np.array_equal(k.transform_x(x.astype(np.float64), seqlen), g[f"z_{avg}"]), avg
+
+
+def test_g18_cfg5_precond_shape(oracle):
+    """BASELINE configs[4]'s shape (d = 512, 32768 RFFs, SRHT width 32768 in float64, rank 2048): features, the
+    compressor, z^T y and the accumulated sketch (through sampled entries and a one-sided probe -- the dense
+    rank x M product and the factorizations are left to the GPU test) against the reference's values."""
+    from test_gpu_cfg_shapes import cfg5_inputs
+    g = load_golden("g18_cfg5_precond.npz")
+    n, d, m, rank = int(g["n"]), int(g["d"]), int(g["num_rffs"]), int(g["rank"])
+    x, y = cfg5_inputs(n, d)
+    assert np.isclose(np.abs(x.astype(np.float64)).sum(), float(g["x_checksum"]), rtol=1e-12)
+    k = orc.OracleKernel("RBF", m, (n, d), g["hyperparams"], 123, ops=oracle)
+    comp = orc.OracleSRHTCompressor(rank, m, random_seed=123, ops=oracle)
+    assert np.array_equal(comp.radem, g["srht_radem"]) and np.array_equal(comp.col_sampler, g["srht_col_sampler"])
+    z8 = k.transform_x(x[:8].astype(np.float64))
+    assert np.array_equal(z8, g["z_first8"])
+    assert np.array_equal(comp.transform_x(z8), g["z8_compressed"])
+    ods = orc.OracleDataset(x.astype(np.float64), y, None, chunk_size=int(g["chunk_size"]))
+    probe_r = np.cos(np.arange(rank) * 0.37)
+    ri, ci = g["acc_sample_rows"], g["acc_sample_cols"]
+    zty, left, samples, yty = np.zeros(m), np.zeros(m), np.zeros(len(ri)), 0.0
+    for xin, yin, _ in ods.get_chunked_data():
+        z = k.transform_x(xin)
+        zty += z.T @ yin
+        yty += float(yin @ yin)
+        sz = comp.transform_x(z)
+        left += (sz @ probe_r) @ z                      # probe_r^T (S(Z)^T Z)
+        samples += np.einsum("ij,ij->j", sz[:, ri], z[:, ci])
+    assert np.allclose(zty, g["zty"], rtol=1e-11, atol=1e-11 * np.abs(g["zty"]).max())
+    assert np.isclose(yty, float(g["yty"]), rtol=1e-12)
+    assert np.allclose(left, g["acc_left"], rtol=1e-9, atol=1e-11 * np.abs(g["acc_left"]).max())
+    assert np.allclose(samples, g["acc_samples"], rtol=1e-9, atol=1e-12 * np.abs(g["acc_samples"]).max())
