@@ -12,7 +12,7 @@ for tag in ("sq1", "sq2"):
     if not f:
         sys.exit(f"missing prof_{tag}")
     for r in csv.DictReader(open(max(f, key=os.path.getmtime))):      # latest merge wins
-        if "wave_ztz_kernel" not in r["Kernel_Name"]:
+        if "wave_ztz_kernel" not in r["Kernel_Name"] and "ztz3_kernel" not in r["Kernel_Name"]:
             continue
         out["kernel_name"] = r["Kernel_Name"][:80]
         out[r["Counter_Name"] if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or tag == "sq1" else "GRBM_GUI_ACTIVE_pass2"] = float(r["Counter_Value"])

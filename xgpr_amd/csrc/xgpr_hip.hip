@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/xgpr_hip.h"
@@ -36,6 +37,7 @@ namespace {
 #include "generic_fht.inc"
 #include "wave_sorf.inc"
 #include "wave_kernels.inc"
+#include "fused_ztz.inc"
 #include "zcache.inc"
 #include "zblock.inc"
 #include "mini_ard.inc"
