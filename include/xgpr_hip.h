@@ -233,6 +233,31 @@ int xgpr_srht_sample_f64(const double *z, const int8_t *radem, const long *sampl
                          double *zty_out, long n, long m, long padded_width, long ncols, long ldo,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the same compressor step from FLOAT32 feature rows (the resident cache / a regenerated window:
+ * Z = scale * zc, Z[:, 0] = 1 when fit_intercept; scale <= 0 selects the RBF-family constant of
+ * xgpr_rbf_feature_cache_f32, a positive scale is for caches that hold complete feature rows): the float64 Z of
+ * rand_nys_constructors.py:113 is never written.  out [n, ldo] float64: columns < ncols as xgpr_srht_sample_f64,
+ * columns ncols .. ldo - 1 zeroed (xgpr_sketch_gemm_f64 reads whole 64-column groups: pass ldo = ncols rounded up
+ * to a multiple of 64).  Any padded width up to 32768 with (padded_width / 8192) * ncols <= 8192: rows beyond the
+ * LDS capacity (cfg5: 32768 float64 = 256 KiB) are transformed block by block, the last stages on the sampled
+ * columns only (bit-identical to pad + SRHT + gather, transform_functions.cpp:95-121). */
+int xgpr_srht_sample_rows_f32(const float *zc, const int8_t *radem, const long *sampler, double *out, const double *y,
+                              double *zty_out, long n, long m, long padded_width, long ncols, long ldo, double scale,
+                              int fit_intercept, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- the dense contractions of the preconditioner passes on the float64 matrix cores, B operand = float32
+ * feature rows (rand_nys_constructors.py:34, :54, :119; the reference calls a library GEMM on float64 Z):
+ *     C[I, J] (+)= sum_k A[k, i] * B(k, j),   B = Z (bt = 0: K = datapoints, J = num_rffs)
+ *                                              B = Z^T (bt = 1: K = num_rffs, J = datapoints)
+ * with Z = scale * zc [n, num_rffs], Z[:, 0] = 1 when fit_intercept (scale as above).  A float64 [K, lda], lda a
+ * multiple of 64 >= I with the columns I .. lda - 1 zero; C float64 [I, ldc] or, trans_out, [J, ldc];
+ * accumulate != 0 adds to C.  Deterministic (contraction ranges are combined in a fixed order).  bt = 1 needs
+ * num_rffs % 4 == 0.  Workspace: xgpr_sketch_gemm_workspace_bytes(I, J, K, ldc, trans_out). */
+size_t xgpr_sketch_gemm_workspace_bytes(long I, long J, long K, long ldc, int trans_out);
+int xgpr_sketch_gemm_f64(const double *A, long lda, const float *zc, long n, long num_rffs, double *C, long ldc,
+                         long I, int bt, int trans_out, double scale, int fit_intercept, int accumulate,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- cudaMiniARDGrad(inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gradArr, fitIntercept)
  * (gpu_rf_gen/xgpr_cuda_rfgen_cpp_ext.cpp:50-60; cpu_rf_gen/rbf_ops/ard_ops.cpp:39-124): MiniARD random
  * features out[n, num_rffs] and their gradient grad[n, num_rffs, num_lengthscales] w.r.t. the per-group

@@ -40,6 +40,7 @@ namespace {
 #include "fused_ztz.inc"
 #include "zcache.inc"
 #include "zblock.inc"
+#include "sketch_gemm.inc"
 #include "mini_ard.inc"
 #include "cg_kernels.inc"
 #include "launchers.inc"
@@ -178,6 +179,22 @@ int xgpr_zty_f32(const float *x, const int8_t *radem, const float *chi, const do
                  size_t workspace_bytes, void *stream) {
     return ztz_impl<false>(x, radem, chi, y, zty_out, n, d, num_rffs, num_freqs, radem_shape2, fit_intercept, workspace,
                            workspace_bytes, stream);
+}
+
+int xgpr_srht_sample_rows_f32(const float *zc, const int8_t *radem, const long *sampler, double *out, const double *y,
+                              double *zty_out, long n, long m, long padded_width, long ncols, long ldo, double scale,
+                              int fit_intercept, void *workspace, size_t workspace_bytes, void *stream) {
+    return srht_sample_rows_impl(zc, radem, sampler, out, y, zty_out, n, m, padded_width, ncols, ldo, scale, fit_intercept,
+                                 workspace, workspace_bytes, stream);
+}
+size_t xgpr_sketch_gemm_workspace_bytes(long I, long J, long K, long ldc, int trans_out) {
+    return sk_geometry(I, J, K, ldc, trans_out).ws_bytes;
+}
+int xgpr_sketch_gemm_f64(const double *A, long lda, const float *zc, long n, long num_rffs, double *C, long ldc,
+                         long I, int bt, int trans_out, double scale, int fit_intercept, int accumulate,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    return sketch_gemm_impl(A, lda, zc, n, num_rffs, C, ldc, I, bt, trans_out, scale, fit_intercept, accumulate, workspace,
+                            workspace_bytes, stream);
 }
 
 int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next, const double *z,

@@ -195,6 +195,12 @@ class SORFKernel(KernelBase):
     def ztz_block_cached(self, zcache, vecs, out, workspace, accumulate=False):
         _block_matvec(zcache, vecs, out, workspace, self.fit_intercept, 0.0, accumulate)
 
+    def row_cache_params(self):
+        """(fit_intercept, scale): Z = scale * cache rows with Z[:, 0] = 1 when fit_intercept -- what the operators
+        that consume float32 rows directly (hipSRHTSampleRows, hipSketchGemm) are told."""
+        return self.fit_intercept, float(np.float32(np.sqrt(1.0 / (self.num_freqs - 0.5 if self.fit_intercept
+                                                                   else self.num_freqs))))
+
     def cache_rows_to_features(self, zrows):
         """float64 feature rows (what transform_x returns) from rows of the float32 cache: the cache holds
         the (cos, sin) values before scaling, the operator widens them and multiplies by its float-typed
@@ -320,6 +326,10 @@ class ConvSORFKernel(KernelBase):
 
     def ztz_block_cached(self, zcache, vecs, out, workspace, accumulate=False):
         _block_matvec(zcache, vecs, out, workspace, False, 1.0, accumulate)
+
+    def row_cache_params(self):
+        """the convolution cache holds complete feature rows (intercept column included): Z = 1.0 * rows"""
+        return False, 1.0
 
     def cache_rows_to_features(self, zrows):
         """the convolution cache holds complete feature rows rounded to float32"""

@@ -8,9 +8,12 @@
   * ``subsampled_srht`` / ``srht_ratio_check`` <-> rand_nys_constructors.py:60-93, :301-357
   * ``check_rank_ratio`` / ``autoselect_preconditioner`` <-> model_baseclass.py:438-480, :376-436
 
-The accumulation passes run per chunk on the device (SORF feature generation and the SRHT of
-the chunk are HIP kernels of libxgpr_hip.so; the dense ``[rank x n] @ [n x M]`` float64
-contractions are plain library GEMMs, rocBLAS through torch).  Per-rank partial sums
+The accumulation passes run on the device over windows of FLOAT32 feature rows (the resident cache, or rows
+regenerated window by window): the compressor step reads them directly (hipSRHTSampleRows: pad + SRHT + gather
++ z^T y in one pass, any padded width up to 32768) and the dense float64 contractions ``S^T Z``, ``Z Q``,
+``Z^T T`` run on the matrix cores with Z widened next to the MFMA (hipSketchGemm) -- a float64 copy of Z is never
+written.  Kernels without float32 rows (or odd shapes the operators do not cover) take the reference's
+formulation: float64 chunks and library GEMMs.  Per-rank partial sums
 (``acc``, ``Z^T y``, ``y^T y``) are combined with one RCCL all-reduce per pass; the small
 factorizations (SVD / QR / Cholesky of M x rank matrices) then run redundantly -- and
 identically -- on every rank (rocSOLVER through torch.linalg), which is cheaper than
@@ -19,7 +22,91 @@ broadcasting U.
 import numpy as np
 import torch
 
+from . import xgpr_hip_rfgen_ext as ext
 from .kernels import SRHTCompressor
+
+ROW_WINDOW_BYTES = 4 << 30        # float32 feature rows regenerated per window of the accumulation passes
+
+
+def _rows_path_ok(dataset, kernel, rank, from_cache, need_bt=False):
+    """Whether the accumulation passes can run on float32 feature rows (module docstring)."""
+    if not hasattr(kernel, "row_cache_params") or torch.device(kernel.device).type != "cuda":
+        return False
+    if not from_cache and not (hasattr(kernel, "fused_ok") and kernel.fused_ok() and hasattr(kernel, "fill_feature_cache")):
+        return False
+    m = kernel.get_num_rffs()
+    if m % 2 != 0 or (need_bt and m % 4 != 0) or not hasattr(dataset, "scaled_x"):
+        return False
+    from .kernels import padded_dims
+    return ext.srht_sample_rows_ok(padded_dims(m), rank, m)
+
+
+def _row_windows(dataset, kernel, from_cache, with_y):
+    """(zc [w, M] float32 feature rows, standardised y [w] or None) over the shard."""
+    m = kernel.get_num_rffs()
+    n = dataset.get_local_ndatapoints()
+    yall = dataset.normalized_y() if with_y else None
+    step = max(8192, ROW_WINDOW_BYTES // (4 * m))
+    if from_cache:
+        zc = dataset.feature_cache(kernel)
+        for lo in range(0, n, step):
+            yield zc[lo:lo + step], (None if yall is None else yall[lo:lo + step])
+        return
+    xs = dataset.scaled_x(kernel.hyperparams[1])
+    step = min(step, max(n, 1))
+    zwin = torch.empty((step, m), dtype=torch.float32, device=xs.device)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        kernel.fill_feature_cache(xs[lo:hi], zwin[:hi - lo])
+        yield zwin[:hi - lo], (None if yall is None else yall[lo:hi])
+
+
+def _srht_pass_rows(dataset, kernel, compressor, acc_results, z_trans_y, from_cache):
+    """single_pass_srht_zty / single_pass_srht (rand_nys_constructors.py:96-123, :39-56) over float32 rows;
+    z_trans_y None: classification, no z^T y.  Returns y^T y (device scalar)."""
+    icpt, scale = kernel.row_cache_params()
+    rank, m = acc_results.shape
+    lds = (rank + 63) // 64 * 64
+    dev = acc_results.device
+    y_trans_y = torch.zeros(1, dtype=torch.float64, device=dev)
+    zty_chunk = None if z_trans_y is None else torch.empty_like(z_trans_y)
+    sws = None if z_trans_y is None else torch.empty(ext.srht_sample_workspace_bytes(m), dtype=torch.uint8, device=dev)
+    sbuf = gws = None
+    for zc, yw in _row_windows(dataset, kernel, from_cache, z_trans_y is not None):
+        w = zc.shape[0]
+        if sbuf is None or sbuf.shape[0] < w:
+            sbuf = torch.empty((w, lds), dtype=torch.float64, device=dev)
+            gws = torch.empty(ext.sketch_gemm_workspace_bytes(rank, m, w, m, False), dtype=torch.uint8, device=dev)
+        sk = sbuf[:w]
+        if z_trans_y is None:
+            ext.hipSRHTSampleRows(zc, compressor.radem, compressor.truncated_sampler, sk, rank, icpt, scale)
+        else:
+            ext.hipSRHTSampleRows(zc, compressor.radem, compressor.truncated_sampler, sk, rank, icpt, scale, yw,
+                                  zty_chunk, sws)
+            z_trans_y += zty_chunk
+            y_trans_y += yw @ yw
+        ext.hipSketchGemm(sk, zc, acc_results, rank, False, False, icpt, scale, accumulate=True, workspace=gws)
+    return y_trans_y
+
+
+def _gauss_pass_rows(dataset, kernel, q_mat, acc_results, from_cache):
+    """single_pass_gauss (rand_nys_constructors.py:18-36): acc[M, rank] += Z^T (Z Q) over float32 rows."""
+    icpt, scale = kernel.row_cache_params()
+    m, rank = acc_results.shape
+    ldq = (rank + 63) // 64 * 64
+    dev = acc_results.device
+    qpad = torch.zeros((m, ldq), dtype=torch.float64, device=dev)
+    qpad[:, :rank] = q_mat
+    tbuf = ws1 = ws2 = None
+    for zc, _ in _row_windows(dataset, kernel, from_cache, False):
+        w = zc.shape[0]
+        if tbuf is None or tbuf.shape[0] < w:
+            tbuf = torch.zeros((w, ldq), dtype=torch.float64, device=dev)       # padding columns stay zero
+            ws1 = torch.empty(ext.sketch_gemm_workspace_bytes(rank, w, m, ldq, True), dtype=torch.uint8, device=dev)
+            ws2 = torch.empty(ext.sketch_gemm_workspace_bytes(rank, m, w, rank, True), dtype=torch.uint8, device=dev)
+        tk = tbuf[:w]
+        ext.hipSketchGemm(qpad, zc, tk, rank, True, True, icpt, scale, workspace=ws1)                    # T = Z Q
+        ext.hipSketchGemm(tk, zc, acc_results, rank, False, True, icpt, scale, accumulate=True, workspace=ws2)   # acc += Z^T T
 
 
 def _feature_chunks(dataset, kernel, with_y, from_cache):
@@ -70,14 +157,21 @@ def _first_pass(dataset, rank, kernel, random_state, verbose, is_regression=True
     comm = dataset.comm
     m = kernel.get_num_rffs()
     compressor = SRHTCompressor(rank, m, device=kernel.device, random_seed=random_state)
+    rows = _rows_path_ok(dataset, kernel, rank, from_cache)
     if not is_regression:
         acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
-        single_pass_srht(dataset, kernel, compressor, acc_results, verbose, from_cache)
+        if rows:
+            _srht_pass_rows(dataset, kernel, compressor, acc_results, None, from_cache)
+        else:
+            single_pass_srht(dataset, kernel, compressor, acc_results, verbose, from_cache)
         comm.all_reduce_(acc_results)
         return acc_results, None, 0, compressor
     acc_results = torch.zeros((rank, m), dtype=torch.float64, device=kernel.device)
     z_trans_y = torch.zeros(m, dtype=torch.float64, device=kernel.device)
-    y_trans_y = single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose, from_cache)
+    if rows:
+        y_trans_y = _srht_pass_rows(dataset, kernel, compressor, acc_results, z_trans_y, from_cache)
+    else:
+        y_trans_y = single_pass_srht_zty(dataset, kernel, compressor, acc_results, z_trans_y, verbose, from_cache)
     comm.all_reduce_(acc_results)
     comm.all_reduce_(z_trans_y)
     comm.all_reduce_(y_trans_y)
@@ -160,7 +254,10 @@ def initialize_srht_multipass(dataset, rank, kernel, random_state, verbose=False
     for _ in range(n_passes - 1):
         q_mat = _orthonormal_basis(acc_results)
         acc_results.zero_()
-        single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose, from_cache)
+        if _rows_path_ok(dataset, kernel, rank, from_cache, need_bt=True):
+            _gauss_pass_rows(dataset, kernel, q_mat, acc_results, from_cache)
+        else:
+            single_pass_gauss(dataset, kernel, q_mat, acc_results, verbose, from_cache)
         comm.all_reduce_(acc_results)
     norm = float(torch.sqrt((acc_results ** 2).sum()).item())
     shift = float(np.spacing(norm))

@@ -174,6 +174,73 @@ def hipSRHTSample(inputArr, radem, sampler, outputArr, ncols=None, yArr=None, zt
                          outputArr.shape[1], wp, wn, _stream()))
 
 
+@_array_args("cacheArr", "radem", "sampler", "outputArr", "yArr", "ztyOut", "workspace")
+def hipSRHTSampleRows(cacheArr, radem, sampler, outputArr, ncols, fitIntercept, scale=0.0, yArr=None, ztyOut=None,
+                      workspace=None):
+    """SRHTCompressor.transform_x (srht_compressor.py:87-97) + the chunk's z^T y (rand_nys_constructors.py:115) from
+    FLOAT32 feature rows (Z = scale * cacheArr, Z[:, 0] = 1 with fitIntercept; scale = 0: the RBF-family constant):
+    ``outputArr[:, :ncols] = cudaSRHT(pad(Z))[:, sampler[:ncols]]`` in float64, remaining columns zeroed.  Any padded
+    width up to 32768 (rows beyond the LDS capacity go block by block)."""
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    r = _dev(radem, "radem", torch.int8, 1)
+    sm = _dev(sampler, "sampler", torch.int64, 1)
+    o = _dev(outputArr, "outputArr", torch.float64, 2)
+    ncols = int(ncols)
+    if outputArr.shape[0] != cacheArr.shape[0] or outputArr.shape[1] < ncols or sampler.shape[0] < ncols:
+        raise RuntimeError("incorrect array dims passed")
+    yp = zp = wp = C.c_void_p(0)
+    wn = C.c_size_t(0)
+    if yArr is not None:
+        yp = _dev(yArr, "yArr", torch.float64, 1)
+        zp = _dev(ztyOut, "ztyOut", torch.float64, 1)
+        if yArr.shape[0] != cacheArr.shape[0] or ztyOut.shape[0] != cacheArr.shape[1]:
+            raise RuntimeError("incorrect array dims passed")
+        if workspace is None:
+            workspace = torch.empty(int(_LIB.xgpr_srht_sample_workspace_bytes(cacheArr.shape[1])), dtype=torch.uint8,
+                                    device=cacheArr.device)
+        wp, wn = C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel())
+    return _lib.check(_LIB.xgpr_srht_sample_rows_f32(zc, r, sm, o, yp, zp, cacheArr.shape[0], cacheArr.shape[1],
+                                                     radem.shape[0], ncols, outputArr.shape[1], float(scale),
+                                                     int(bool(fitIntercept)), wp, wn, _stream()))
+
+
+def srht_sample_rows_ok(padded_width, ncols, num_rffs):
+    """Whether hipSRHTSampleRows covers this shape (see include/xgpr_hip.h)."""
+    nb = max(1, padded_width // 8192)
+    return padded_width <= 32768 and (nb == 1 or (nb * ncols <= 8192 and num_rffs % 4 == 0))
+
+
+@_array_args("aMat", "cacheArr", "outArr", "workspace")
+def hipSketchGemm(aMat, cacheArr, outArr, nrows, bt, transOut, fitIntercept, scale=0.0, accumulate=False, workspace=None):
+    """``outArr (+)= aMat[:, :nrows].T @ Z`` (bt False: aMat [n, lda], outArr [nrows, num_rffs] or transposed) or
+    ``aMat[:, :nrows].T @ Z.T`` (bt True: aMat [num_rffs, lda], outArr [nrows, n] or transposed) on the float64 matrix
+    cores, Z = scale * cacheArr float32 rows with Z[:, 0] = 1 when fitIntercept -- the dense products of
+    rand_nys_constructors.py:34, :54, :119 without a float64 copy of Z.  aMat's row pitch must be a multiple of 64
+    with zeros beyond column nrows."""
+    ap = _dev(aMat, "aMat", torch.float64, 2)
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    op = _dev(outArr, "outArr", torch.float64, 2)
+    n, m = cacheArr.shape
+    nrows = int(nrows)
+    jdim, kdim = (n, m) if bt else (m, n)
+    if aMat.shape[0] != kdim or aMat.shape[1] < nrows:
+        raise RuntimeError("incorrect array dims passed")
+    want = (jdim, nrows) if transOut else (nrows, jdim)
+    if outArr.shape[0] != want[0] or outArr.shape[1] < want[1]:
+        raise RuntimeError("incorrect array dims passed")
+    need = int(_LIB.xgpr_sketch_gemm_workspace_bytes(nrows, jdim, kdim, outArr.shape[1], int(bool(transOut))))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=cacheArr.device)
+    return _lib.check(_LIB.xgpr_sketch_gemm_f64(ap, aMat.shape[1], zc, n, m, op, outArr.shape[1], nrows, int(bool(bt)),
+                                                int(bool(transOut)), float(scale), int(bool(fitIntercept)),
+                                                int(bool(accumulate)), C.c_void_p(workspace.data_ptr()),
+                                                C.c_size_t(workspace.numel()), _stream()))
+
+
+def sketch_gemm_workspace_bytes(nrows, jdim, kdim, ldc, trans_out):
+    return int(_LIB.xgpr_sketch_gemm_workspace_bytes(nrows, jdim, kdim, ldc, int(bool(trans_out))))
+
+
 def srht_sample_workspace_bytes(m):
     return int(_LIB.xgpr_srht_sample_workspace_bytes(m))
 
