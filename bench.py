@@ -18,10 +18,13 @@ preconditioner apply and the float64 vector updates, including the per-iteration
 check.  value = N * M * K / t  random features per second (whole job); cg_iters_per_sec = K / t.
 
 Besides the contract fields the JSON line carries
-  roofline      -- the dominant kernel (wave_ztz_kernel): algorithmic HBM bytes (4*d per row)
+  roofline      -- the dominant kernel (ztz3_kernel, the fused matvec): algorithmic HBM bytes (4*d per row)
                    over its measured duration (HIP events on the launch stream)
   featgen_op    -- the stand-alone cudaRBFFeatureGen-equivalent operator (Z materialised as
                    float64), with its own HBM roofline (4*d + 8*M bytes per row)
+  precond_build -- the randomized-Nystrom build that precedes the timed steps: its dense work 2*N*rank*M
+                   float64 flop over its wall time, against the FP64 matrix peak
+  distributed   -- ranks the all-reduce summed over, per-rank step / kernel / all-reduce times
   cpu_baseline  -- the CPU oracle (OpenMP port of the reference CPU algorithm) timed on this
                    box's host cores on a bounded row sample (rank 0, --gpus 1 only)
 """
@@ -346,7 +349,7 @@ def main():
         cbytes = 4.0 * m * (hi - lo)
         ctraffic = None
         try:   # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (profiles/r1_pmc_traffic_cached.json)
-            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
+            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
         except (OSError, KeyError, ValueError):
             pass
         cached = {"ms_per_step": 1e3 * float(tc.item()) / args.steps, "cg_iters_per_sec": args.steps / float(tc.item()),
@@ -390,7 +393,7 @@ def main():
         ds._zcache_key = None
 
     # stand-alone feature-generation operator (Z materialised, float64), this rank's device
-    fg_rows = min(16384, hi - lo)
+    fg_rows = min(131072, hi - lo)      # 9.1 GB per call: a ~1.7 ms window, not a launch-noise-sized one
     xs = ds.scaled_x(1.0)[:fg_rows]
     zbuf = torch.empty((fg_rows, m), dtype=torch.float64, device=device)
     for _ in range(2):
@@ -407,24 +410,25 @@ def main():
 
     if comm.rank == 0:
         n_local = hi - lo
-        # HBM bytes per launch of the dominant kernel from the PMC counters (collected in separate
+        # HBM bytes per launch of the dominant kernel from the PMC counters: a STORED measurement (separate
         # rocprofv3 --pmc passes of this same command, corrected as MI355X_MICROARCH.md prescribes;
-        # see profiles/r1_pmc_traffic.json) -- only quoted when it was measured on this configuration
+        # profiles/r2_pmc_traffic.json), not a quantity of this run -- quoted only for the configuration it was
+        # measured on, and labelled as such in the line
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
             c = pm["config"]
             if (c["rows_per_gpu"], c["dim"], c["rffs"]) == (n_local, d, m):
                 traffic = pm["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         # the resource this kernel is actually bound by: vector-instruction issue.  Instructions per wave tile
-        # (1024 frequencies of one datapoint) from the SQ counters of this kernel (profiles/r1_fused_pmc_sq.json,
+        # (1024 frequencies of one datapoint) from the SQ counters of this kernel (profiles/r2_fused_pmc_sq.json,
         # cfg3 shape) x the tiles of this launch / the live kernel time, against one VALU issue per SIMD every 4
         # cycles at the 2.4 GHz peak clock
         vector_pipe = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_fused_pmc_sq.json")))["wave_ztz_kernel"]["derived"]
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r2_fused_pmc_sq.json")))["wave_ztz_kernel"]["derived"]
             if (d, m) == (1024, 8192):
                 tiles = n_local * ((m // 2 + 1023) // 1024)
                 peak_inst = 256 * 4 * 2.4e9 / 4
@@ -456,13 +460,15 @@ def main():
                                    "rank-%d SRHT preconditioner (all rows), CG step" %
                                    (n, d, m, args.gpus, args.rank_precond),
                        "rows_per_gpu": n_local, "lambda": 0.1, "sigma": 1.0},
-            "roofline": {"kernel": "wave_ztz_kernel<10, true> (+ pack_radem, reduce_slabs)", "bound": "hbm",
+            "roofline": {"kernel": "ztz3_kernel<10> (+ pack_radem, reduce_slabs)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc passes of this "
+                         "command; stored, not re-measured in this run)" if traffic is not None else None,
+                         "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
                          "vector_pipe": vector_pipe,
                          "note": "HBM traffic of this kernel is only the X read; the binding resources are the vector pipe "
-                                 "(butterflies + sincos; 65 % busy at 2 waves/SIMD) and LDS-exchange latency: "
-                                 "profiles/r1_fused_pmc_sq.json, DESIGN.md section 3"},
+                                 "(butterflies + sincos) and LDS-exchange latency at 3 waves/SIMD: "
+                                 "profiles/r2_fused_pmc_sq.json, DESIGN.md section 3"},
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},
@@ -474,7 +480,16 @@ def main():
                                               "the compute stream with events); allreduce_ms_per_iter is measured by HIP "
                                               "events on the compute stream around the call, inside the timed CG iterations"},
             "final_loss": losses[-1],
-            "precond_build_s": precond_build_s,
+            "precond_build": {"seconds": precond_build_s, "rows": n, "rank": args.rank_precond, "method": "srht",
+                              "flops": 2.0 * n * args.rank_precond * m,
+                              "roofline": {"kernel": "sketch_gemm_kernel<false, false> (S^T Z on v_mfma_f64_16x16x4_f64, float32 Z rows) "
+                                                     "+ srht_sample_rows_kernel + wave_rbf_kernel (cache rows)", "bound": "mfma",
+                                           "achieved": 2.0 * n * args.rank_precond * m / precond_build_s / 1e12 / args.gpus,
+                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": 2.0 * n * args.rank_precond * m / precond_build_s / 1e12 / args.gpus / FP64_MFMA_PEAK_TFLOPS,
+                                           "traffic": None},
+                              "note": "whole build (feature rows, SRHT + sample, contraction, all-reduce, factorizations) over the "
+                                      "flops of the contraction alone; per GPU"},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-ROUND = "r1"
+ROUND = "r2"
 
 
 def one(pattern):
@@ -19,7 +19,7 @@ def one(pattern):
 
 
 shutil.copy(one("prof_stats/*/*kernel_stats.csv"), os.path.join(P, f"{ROUND}_bench_n1_kernel_stats.csv"))
-KERNELS = {"wave_ztz_kernel": "fused", "zcache_ztz_kernel": "cached", "zblock_t_kernel": "block_t", "zblock_w_kernel": "block_w",
+KERNELS = {"ztz3_kernel": "fused", "sketch_gemm_kernel": "sketch_gemm", "srht_sample_rows_kernel": "srht_rows", "zcache_ztz_kernel": "cached", "zblock_t_kernel": "block_t", "zblock_w_kernel": "block_w",
            "reduce_slabs_kernel": "reduce", "wave_rbf_kernel": "featgen"}
 per = {}
 for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -51,13 +51,13 @@ def mean_main(vals):
 
 note = ("gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; "
         "separate --pmc passes with --kernel-trace only (tools/collect_profiles.sh)")
-for short, kname, alg in (("fused", "wave_ztz_kernel<10, true, true>", 4.0 * d * n_local),
+for short, kname, alg in (("fused", "ztz3_kernel<10>", 4.0 * d * n_local),
                           ("cached", "zcache_ztz_kernel<true, 2>", 4.0 * m * n_local)):
     if short not in per:
         continue
     fk, wk = mean_main(per[short]["FETCH_SIZE"]), mean_main(per[short]["WRITE_SIZE"])
     hbm = (2.0 * fk + wk) * 1024.0
-    out = {"round": 1, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
+    out = {"round": 2, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
            "--steps 3 --warmup 1 --no-cpu-baseline", "kernel": kname,
            "config": {"rows_per_gpu": n_local, "dim": d, "rffs": m, "n_gpus": 1},
            "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk, "correction": note,
@@ -69,3 +69,20 @@ for short in ("block_t", "block_w"):
     if short in per:
         fk, wk = mean_main(per[short]["FETCH_SIZE"]), mean_main(per[short]["WRITE_SIZE"])
         print(short, f"HBM bytes per launch {(2 * fk + wk) * 1024 / 1e9:.2f} GB (cache read algorithmic {4.0 * m * n_local / 1e9:.2f} GB)")
+
+# the preconditioner pass over float32 feature rows (windows of ROW_WINDOW_BYTES / (4 M) rows, rank 512): the largest
+# launches are the full windows
+win = min(n_local, max(8192, (4 << 30) // (4 * m)))
+rank = 512
+pre = {}
+for short, kname, alg in (("sketch_gemm", "sketch_gemm_kernel<false, false>", win * (rank * 8.0 + m * 4.0) + rank * m * 8.0),
+                          ("srht_rows", "srht_sample_rows_kernel<1>", win * (m * 4.0 + rank * 8.0))):
+    if short in per:
+        fk, wk = max(per[short]["FETCH_SIZE"]), max(per[short]["WRITE_SIZE"])
+        hbm = (2.0 * fk + wk) * 1024.0
+        pre[short] = {"kernel": kname, "rows_per_launch": win, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+                      "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg}
+        print(short, f"traffic/algorithmic = {hbm / alg:.4f}")
+if pre:
+    pre["correction"] = note
+    json.dump(pre, open(os.path.join(P, f"{ROUND}_pmc_traffic_precond.json"), "w"), indent=1)
