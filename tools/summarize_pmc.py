@@ -19,7 +19,7 @@ def one(pattern):
 
 
 shutil.copy(one("prof_stats/*/*kernel_stats.csv"), os.path.join(P, f"{ROUND}_bench_n1_kernel_stats.csv"))
-KERNELS = {"ztz3_kernel": "fused", "sketch_gemm_kernel": "sketch_gemm", "srht_sample_rows_kernel": "srht_rows", "zcache_ztz_kernel": "cached", "zblock_t_kernel": "block_t", "zblock_w_kernel": "block_w",
+KERNELS = {"ztz3_kernel": "fused", "sketch_gemm_kernel": "sketch_gemm", "srht_sample_rows": "srht_rows", "zcache_ztz_kernel": "cached", "zblock_t_kernel": "block_t", "zblock_w_kernel": "block_w",
            "reduce_slabs_kernel": "reduce", "wave_rbf_kernel": "featgen"}
 per = {}
 for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -76,7 +76,7 @@ win = min(n_local, max(8192, (4 << 30) // (4 * m)))
 rank = 512
 pre = {}
 for short, kname, alg in (("sketch_gemm", "sketch_gemm_kernel<false, false>", win * (rank * 8.0 + m * 4.0) + rank * m * 8.0),
-                          ("srht_rows", "srht_sample_rows_kernel<1>", win * (m * 4.0 + rank * 8.0))):
+                          ("srht_rows", "srht_sample_rows16_kernel<13>", win * (m * 4.0 + rank * 8.0))):
     if short in per:
         fk, wk = max(per[short]["FETCH_SIZE"]), max(per[short]["WRITE_SIZE"])
         hbm = (2.0 * fk + wk) * 1024.0
