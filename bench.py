@@ -380,13 +380,14 @@ def main():
             bflop = 4.0 * (hi - lo) * m * kb
             cached["block_matvec_k26"] = {
                 "ms_per_matvec": b_ms,
-                "roofline": {"kernel": "zblock_t_kernel<2,4> + zblock_w_kernel<2> (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                "roofline": {"kernel": "zblock_t_kernel<1,4,3> + zblock_w_kernel<1,3> (v_mfma_f64_16x16x4_f64 for columns 0-15, "
+                                       "v_mfma_f64_4x4x4_4b_f64 for columns 16-27)", "bound": "mfma",
                              "achieved": bflop / (b_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": bflop / (b_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                             "issued": bflop * 32 / kb / (b_ms * 1e-3) / 1e12, "traffic": None,
+                             "issued": bflop * 28 / kb / (b_ms * 1e-3) / 1e12, "traffic": None,
                              "algorithmic_flops": bflop},
-                "note": "26 right-hand sides are padded to 32 columns: 'issued' counts the padded MFMA work; "
-                        "MFMA-busy counters in profiles/r1_nmll_block_pmc_mfma.csv"}
+                "note": "26 right-hand sides run as 16 + 3 x 4 columns: 'issued' counts the 28 columns of MFMA work; "
+                        "DESIGN.md section 3 (block of right-hand sides)"}
             del vb, wb, bws
         del zc
         ds._zcache = None
