@@ -147,3 +147,29 @@ def test_offline_dataset_on_device(tmp_path):
     w0, n0, _ = cg_fit_lib_internal(kern, off, 1e-8, 200, None, False, cache_features=False)
     w1, n1, _ = cg_fit_lib_internal(kern, ref, 1e-8, 200, None, False, cache_features=False)
     assert n0 == n1 and torch.equal(w0, w1)
+
+
+@pytest.mark.parametrize("n,d,m,icpt", [(1, 1024, 8192, True), (5, 1024, 8192, True), (769, 1024, 8192, False),
+                                        (3000, 128, 4096, True), (2500, 300, 6144, True), (2048, 512, 8192, False),
+                                        (1000, 1000, 8192, True), (777, 256, 12288, True), (600, 130, 4096, True),
+                                        (900, 20, 4096, True), (1500, 512, 16384, True), (40, 64, 2048, True)])
+def test_fused_matvec_shapes_around_the_three_wave_kernel(n, d, m, icpt):
+    """The fused CG matvec over the shapes that decide which kernel serves it -- the three-wave kernel (128 <= P <= 1024,
+    2 / 3 / 4 / 6 tiles per datapoint, rows a multiple of 4 floats), the two-wave kernel (everything else: one tile,
+    P < 128, d % 4 != 0, M = 12288 / 16384 without LDS room) -- incl. fewer datapoints than datapoint slots, zero-padded
+    widths and odd log2 P: equal to Z^T (Z v) from the stand-alone operator's float64 Z, and deterministic."""
+    from xgpr_amd.kernels import make_kernel, scale_input
+    g = torch.Generator(device=DEV).manual_seed(n + d + m)
+    x = torch.randn(n, d, generator=g, device=DEV) / np.sqrt(d)
+    kern = make_kernel("RBF", (n, d), m, 123, DEV, {"intercept": icpt})
+    kern.set_hyperparams(np.array([0.1, 1.1]), logspace=False)
+    xs = scale_input(x, kern.hyperparams[1])
+    v = torch.randn(m, generator=g, device=DEV, dtype=torch.float64)
+    w = torch.zeros(m, dtype=torch.float64, device=DEV)
+    kern.ztz_matvec(xs, v, w)
+    z = kern.transform_x(x)
+    ref = z.T @ (z @ v)
+    assert float((w - ref).abs().max()) <= 1e-9 * float(ref.abs().max())
+    w2 = torch.zeros_like(w)
+    kern.ztz_matvec(xs, v, w2)
+    assert torch.equal(w, w2)
