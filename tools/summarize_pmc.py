@@ -75,7 +75,7 @@ for short in ("block_t", "block_w"):
 win = min(n_local, max(8192, (4 << 30) // (4 * m)))
 rank = 512
 pre = {}
-for short, kname, alg in (("sketch_gemm", "sketch_gemm_kernel<false, false>", win * (rank * 8.0 + m * 4.0) + rank * m * 8.0),
+for short, kname, alg in (("sketch_gemm", "sketch_gemm_lds_kernel<false>", win * (rank * 8.0 + m * 4.0) + 2 * rank * m * 8.0),
                           ("srht_rows", "srht_sample_rows16_kernel<13>", win * (m * 4.0 + rank * 8.0))):
     if short in per:
         fk, wk = max(per[short]["FETCH_SIZE"]), max(per[short]["WRITE_SIZE"])
