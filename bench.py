@@ -483,7 +483,7 @@ def main():
             "final_loss": losses[-1],
             "precond_build": {"seconds": precond_build_s, "rows": n, "rank": args.rank_precond, "method": "srht",
                               "flops": 2.0 * n * args.rank_precond * m,
-                              "roofline": {"kernel": "sketch_gemm_kernel<false, false> (S^T Z on v_mfma_f64_16x16x4_f64, float32 Z rows) "
+                              "roofline": {"kernel": "sketch_gemm_lds_kernel<false> (S^T Z on v_mfma_f64_16x16x4_f64, float32 Z rows, operand tiles through LDS) "
                                                      "+ srht_sample_rows_kernel + wave_rbf_kernel (cache rows)", "bound": "mfma",
                                            "achieved": 2.0 * n * args.rank_precond * m / precond_build_s / 1e12 / args.gpus,
                                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
