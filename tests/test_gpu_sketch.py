@@ -16,15 +16,19 @@ def _z64(zc, scale, icpt):
     return z
 
 
-@pytest.mark.parametrize("n,m,r,icpt,scale", [(4096, 1024, 64, True, 0.031), (1000, 516, 37, False, 1.0),
-                                               (5003, 2048, 200, True, 0.02), (16384, 8192, 512, True, 0.0156),
-                                               (70, 128, 5, True, 0.5)])
-def test_sketch_gemm_contract_datapoints(n, m, r, icpt, scale):
+@pytest.mark.parametrize("n,m,r,icpt,scale,pad", [
+    (4096, 1024, 64, True, 0.031, 64), (1000, 516, 37, False, 1.0, 64), (5003, 2048, 200, True, 0.02, 64),
+    (16384, 8192, 512, True, 0.0156, 64), (70, 128, 5, True, 0.5, 64),
+    # the LDS-staged kernel (features and padded rank multiples of 128): one chunk, an odd chunk count, a tail of
+    # K % 16 rows, ragged row tiles, with and without the intercept column, many contraction ranges
+    (16, 256, 128, True, 0.07, 128), (48, 256, 128, False, 0.07, 128), (1031, 384, 129, True, 0.05, 128),
+    (8192 + 16, 1024, 300, False, 0.03, 128), (100000, 256, 70, True, 0.088, 128)])
+def test_sketch_gemm_contract_datapoints(n, m, r, icpt, scale, pad):
     """C[r, M] (+)= S^T Z and its transposed store, ragged shapes, several contraction ranges."""
     from xgpr_amd import xgpr_hip_rfgen_ext as ext
     g = torch.Generator(device=DEV).manual_seed(n + m)
     zc = torch.rand(n, m, generator=g, device=DEV) * 2 - 1
-    lda = (r + 63) // 64 * 64
+    lda = (r + pad - 1) // pad * pad
     s = torch.zeros(n, lda, dtype=torch.float64, device=DEV)
     s[:, :r] = torch.randn(n, r, generator=g, device=DEV, dtype=torch.float64)
     ref = s[:, :r].T @ _z64(zc, scale, icpt)
