@@ -46,21 +46,34 @@ def test_sketch_gemm_contract_datapoints(n, m, r, icpt, scale, pad):
     assert torch.equal(again, out_t)                    # deterministic
 
 
-@pytest.mark.parametrize("n,m,r,icpt,scale", [(4096, 1024, 64, True, 0.031), (1001, 516, 37, False, 1.0),
-                                               (3000, 8192, 512, True, 0.0156), (65, 128, 5, True, 0.5)])
-def test_sketch_gemm_contract_features(n, m, r, icpt, scale):
-    """T[n, r] = Z Q (stored through the transposed epilogue): the first product of single_pass_gauss."""
+@pytest.mark.parametrize("n,m,r,icpt,scale,pad", [
+    (4096, 1024, 64, True, 0.031, 64), (1001, 516, 37, False, 1.0, 64), (3000, 8192, 512, True, 0.0156, 64),
+    (65, 128, 5, True, 0.5, 64),
+    # the LDS-staged kernel (features a multiple of 16, padded rank a multiple of 128): one chunk, an odd chunk count,
+    # ragged datapoint tiles (clamped rows), ragged row tiles, many contraction ranges (intercept added by range 0 only)
+    (16, 16, 128, True, 0.3, 128), (130, 48, 128, False, 0.2, 128), (130, 4096, 128, True, 0.02, 128),
+    (5000, 1024, 300, True, 0.03, 128), (1, 256, 129, True, 0.07, 128)])
+def test_sketch_gemm_contract_features(n, m, r, icpt, scale, pad):
+    """T[n, r] = Z Q (stored through the transposed epilogue) and its untransposed form [r, n]: the first product of
+    single_pass_gauss."""
     from xgpr_amd import xgpr_hip_rfgen_ext as ext
     g = torch.Generator(device=DEV).manual_seed(n * 3 + m)
     zc = torch.rand(n, m, generator=g, device=DEV) * 2 - 1
-    lda = (r + 63) // 64 * 64
+    lda = (r + pad - 1) // pad * pad
     q = torch.zeros(m, lda, dtype=torch.float64, device=DEV)
     q[:, :r] = torch.randn(m, r, generator=g, device=DEV, dtype=torch.float64)
     ref = _z64(zc, scale, icpt) @ q[:, :r]
+    tol = 1e-13 * float(ref.abs().max()) * np.sqrt(m)
     t = torch.zeros((n, lda), dtype=torch.float64, device=DEV)
     ext.hipSketchGemm(q, zc, t, r, True, True, icpt, scale)
-    assert float((t[:, :r] - ref).abs().max()) <= 1e-13 * float(ref.abs().max()) * np.sqrt(m)
+    assert float((t[:, :r] - ref).abs().max()) <= tol
     assert float(t[:, r:].abs().max()) == 0.0 if lda > r else True      # the padding columns stay zero
+    ldc = (n + 1) // 2 * 2
+    u = torch.zeros((r, ldc), dtype=torch.float64, device=DEV)
+    ext.hipSketchGemm(q, zc, u, r, True, False, icpt, scale)
+    assert float((u[:, :n] - ref.T).abs().max()) <= tol
+    ext.hipSketchGemm(q, zc, u, r, True, False, icpt, scale, accumulate=True)
+    assert float((u[:, :n] - 2 * ref.T).abs().max()) <= 2 * tol
 
 
 @pytest.mark.parametrize("n,m,rank,icpt", [(300, 4100, 256, True), (257, 8192, 512, True), (100, 1000, 100, False),
