@@ -86,8 +86,8 @@ def dist_summary(comm, device, m):
     ones = torch.ones(1, dtype=torch.float64, device=device)
     comm.all_reduce_(ones)
     out = {"n_ranks_seen": int(round(float(ones.item()))), "world_size": comm.world_size,
-           "backend": dist.get_backend() if comm.world_size > 1 else "none (single rank)"}
-    if comm.world_size > 1:
+           "backend": dist.get_backend() if comm.through_backend else "none (single rank)"}
+    if comm.through_backend:
         w = torch.zeros(m, dtype=torch.float64, device=device)
         for _ in range(5):
             comm.all_reduce_(w)
@@ -115,7 +115,7 @@ def gather_per_rank(comm, device, values):
     import torch
     import torch.distributed as dist
     mine = torch.tensor(values, dtype=torch.float64, device=device)
-    if comm.world_size == 1:
+    if not comm.through_backend:
         return [mine.tolist()]
     bufs = [torch.zeros_like(mine) for _ in range(comm.world_size)]
     dist.all_gather(bufs, mine)
@@ -202,7 +202,7 @@ def main():
         info["shard_rows_per_rank"] = [r[0] for r in gather_per_rank(comm, device, [float(hi - lo)])]
         if comm.rank == 0:
             print(json.dumps({"dist_check": True, "n_gpus": args.gpus, **info}))
-        if comm.world_size > 1:
+        if comm.through_backend:
             torch.distributed.destroy_process_group()
         return
     from xgpr_amd import dist as xd
@@ -262,7 +262,7 @@ def main():
     orig_ar = comm.all_reduce_
 
     def timed_all_reduce(tensor):
-        if comm.world_size == 1:
+        if not comm.through_backend:
             return tensor
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -290,7 +290,7 @@ def main():
     t1 = time.perf_counter()
     assert niter == args.steps
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
-    if comm.world_size > 1:
+    if comm.through_backend:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     t = float(elapsed.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in timings]))
@@ -342,7 +342,7 @@ def main():
         torch.cuda.synchronize()
         comm.barrier()
         tc = torch.tensor([time.perf_counter() - tc0], dtype=torch.float64, device=device)
-        if comm.world_size > 1:
+        if comm.through_backend:
             torch.distributed.all_reduce(tc, op=torch.distributed.ReduceOp.MAX)
         ck_ms = float(np.mean([a.elapsed_time(b) for a, b in ctimes]))
         kern.ztz_matvec_cached = origc
@@ -497,7 +497,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if comm.world_size > 1:
+    if comm.through_backend:
         torch.distributed.destroy_process_group()
 
 

@@ -17,8 +17,11 @@ import torch.distributed as dist
 class Comm:
     """Rank / world-size holder with a sum all-reduce that is a no-op for one rank."""
 
-    def __init__(self, rank=0, world_size=1, group=None):
+    def __init__(self, rank=0, world_size=1, group=None, through_backend=False):
         self.rank, self.world_size, self.group = rank, world_size, group
+        # one-rank rehearsal of the collective path (XGPR_DIST_FORCE=1): the calls go to the backend even though
+        # there is nobody to exchange with, so that communicator set-up and stream ordering are exercised on one GPU
+        self.through_backend = through_backend or world_size > 1
 
     @property
     def is_distributed(self):
@@ -26,18 +29,18 @@ class Comm:
 
     def all_reduce_(self, tensor):
         """In-place sum over ranks (RCCL ring / tree over xGMI on GPUs)."""
-        if self.world_size > 1:
+        if self.through_backend:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
     def all_reduce_max_(self, tensor):
         """In-place maximum over ranks (dataset statistics only)."""
-        if self.world_size > 1:
+        if self.through_backend:
             dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=self.group)
         return tensor
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.through_backend:
             dist.barrier(group=self.group)
 
     def shard_bounds(self, n):
@@ -64,7 +67,8 @@ def init_from_env(device_type="cuda"):
         local = int(os.environ["XGPR_LOCAL_DEVICE"])
     if device_type == "cuda":
         torch.cuda.set_device(local)
-    if world == 1:
+    force = os.environ.get("XGPR_DIST_FORCE", "") == "1"
+    if world == 1 and not force:
         return Comm()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
@@ -74,4 +78,4 @@ def init_from_env(device_type="cuda"):
         if device_type == "cuda" and backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
-    return Comm(rank, world)
+    return Comm(rank, world, through_backend=force)
