@@ -78,9 +78,10 @@ pre = {}
 for short, kname, alg in (("sketch_gemm", "sketch_gemm_lds_kernel<false>", win * (rank * 8.0 + m * 4.0) + 2 * rank * m * 8.0),
                           ("srht_rows", "srht_sample_rows16_kernel<13>", win * (m * 4.0 + rank * 8.0))):
     if short in per:
-        fk, wk = max(per[short]["FETCH_SIZE"]), max(per[short]["WRITE_SIZE"])
+        fk, wk = max(per[short]["FETCH_SIZE"]), max(per[short]["WRITE_SIZE"])      # the largest = a full window
         hbm = (2.0 * fk + wk) * 1024.0
         pre[short] = {"kernel": kname, "rows_per_launch": win, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+                      "FETCH_SIZE_KiB_all_launches": sorted(per[short]["FETCH_SIZE"]),
                       "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg}
         print(short, f"traffic/algorithmic = {hbm / alg:.4f}")
 if pre:
