@@ -295,7 +295,8 @@ def test_conv_preconditioned_cg_sharing_one_feature_pass_matches_oracle(oracle, 
     kern.transform_x = counting
     pre = RandNysPreconditioner(kern, ds, 32, False, 123, method)
     w, niter, _ = cg_fit_lib_internal(kern, ds, 1e-9, 300, pre, False, cache_features=True)
-    assert calls["n"] == 4                          # ceil(500 / 128) chunks, generated exactly once
+    step = min(kern.CACHE_BUILD_ROWS, (1 << 30) // (8 * m))
+    assert calls["n"] == -(-n // step)              # every sequence generated exactly once (in cache-build windows)
     ods = orc.OracleDataset(x.astype(np.float64), y, sl, chunk_size=128)
     okern = orc.OracleKernel("Conv1dRBF", m, x.shape, hp, 123, conv_width=5, averaging="sqrt", ops=oracle)
     opre = orc.OracleRandNysPreconditioner(okern, ods, 32, 123, method)

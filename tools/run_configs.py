@@ -45,8 +45,11 @@ kern.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
 # one small untimed build first: the first GEMM / eigensolver / Cholesky calls of a process pay ~0.4 s of library
 # initialisation that is not part of a build
 nw = min(n, 4096)
-RandNysPreconditioner(kern, build_regression_dataset(x[:nw], y[:nw], None if sl is None else sl[:nw], chunk_size=chunk, device=dev),
-                      min(rank, 256), False, 123, method)
+ds_w = build_regression_dataset(x[:nw], y[:nw], None if sl is None else sl[:nw], chunk_size=chunk, device=dev)
+pre_w = RandNysPreconditioner(kern, ds_w, min(rank, 256), False, 123, method)
+for cache in (False, True) if which != "cfg4" else (True,):      # first launches of the fit's kernels, untimed as well
+    cg_fit_lib_internal(kern, ds_w, 1e-6, 5, pre_w, False, cache_features=cache)
+del ds_w, pre_w
 if hasattr(ds, "_zcache"):
     ds._zcache = None
 pre, t_pre = sync_time(lambda: RandNysPreconditioner(kern, ds, rank, False, 123, method))

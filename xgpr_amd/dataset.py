@@ -79,6 +79,14 @@ class DeviceDataset:
             lchunk = None if self._sequence_lengths is None else self._sequence_lengths[i:j]
             yield self._xdata[i:j, ...], lchunk
 
+    def get_xdata(self):
+        """The whole resident shard of x (device tensor)."""
+        return self._xdata
+
+    def get_sequence_lengths(self):
+        """Host int32 sequence lengths of the shard, or None."""
+        return self._sequence_lengths
+
     def feature_cache(self, kernel):
         """float32 feature cache of the whole shard for ``kernel`` at its current sigma (rebuilt when
         the kernel object or sigma changes)."""
