@@ -70,6 +70,13 @@ size_t xgpr_rbf_workspace_bytes(long radem_shape2);
  * generic path.  `width` is the un-padded transform width (d, or conv_width * C);
  * elem_size is sizeof(T). */
 size_t xgpr_sorf_workspace_bytes(long radem_shape2, long width, int elem_size);
+/* Workspace of the convolution operators (xgpr_conv1d_fgen_*, xgpr_conv_grad_*, xgpr_conv1d_maxpool_*) with room
+ * for the processing order of the nseq sequences: given at least this much, a launch runs its longest sequences
+ * first (a wave runs for as long as its sequence has k-mers; in the caller's order the long sequences at the end of
+ * a chunk leave most of the GPU idle).  With only xgpr_sorf_workspace_bytes the operators run in the caller's order;
+ * results are the same either way.  No reference counterpart: the reference allocates its scratch per call
+ * (gpu_rf_gen/convolution_ops/rbf_convolution.cu:368-379). */
+size_t xgpr_conv_workspace_bytes(long radem_shape2, long width, int elem_size, long nseq);
 int xgpr_rbf_feature_gen_f32(const float *x, double *out, const int8_t *radem, const float *chi,
                              long n, long d, long out_rows, long num_rffs, long num_freqs,
                              long radem_shape2, int fit_intercept,

@@ -53,6 +53,7 @@ SIGNATURES = {
 SIZE_FUNCS = {
     "xgpr_rbf_workspace_bytes": [_l],
     "xgpr_sorf_workspace_bytes": [_l, _l, _i],
+    "xgpr_conv_workspace_bytes": [_l, _l, _i, _l],
     "xgpr_precond_apply_workspace_bytes": [_l],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
     "xgpr_zcache_block_workspace_bytes": [_l, _l, _l],

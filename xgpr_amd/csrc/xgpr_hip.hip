@@ -66,6 +66,9 @@ int xgpr_srht_f64(double *x, const int8_t *radem, long n, long dim, long radem_l
 }
 
 size_t xgpr_rbf_workspace_bytes(long radem_shape2) { return masks_bytes(radem_shape2); }
+size_t xgpr_conv_workspace_bytes(long radem_shape2, long width, int elem_size, long nseq) {
+    return xgpr_sorf_workspace_bytes(radem_shape2, width, elem_size) + align_up((size_t)(nseq > 0 ? nseq : 0) * sizeof(int32_t), 256);
+}
 size_t xgpr_sorf_workspace_bytes(long radem_shape2, long width, int elem_size) {
     const size_t a = masks_bytes(radem_shape2);
     const size_t b = generic_scratch_bytes(padded_width(width), (size_t)elem_size);

@@ -94,6 +94,12 @@ def _sorf_ws(radem, width, inputArr):
     return _workspace(nbytes, inputArr.device)
 
 
+def _conv_ws(radem, width, inputArr):
+    """Workspace of a convolution operator call, with room for the longest-first processing order."""
+    nbytes = _LIB.xgpr_conv_workspace_bytes(radem.shape[2], int(width), inputArr.element_size(), inputArr.shape[0])
+    return _workspace(nbytes, inputArr.device)
+
+
 def _seqlens(seqlengths, device):
     """Host int32 array (validated by the library on the host) + its device copy."""
     if isinstance(seqlengths, torch.Tensor):
@@ -309,7 +315,7 @@ def hipConv1dFGen(inputArr, outputArr, radem, chiArr, seqlengths, convWidth, sca
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
     host, dev = _seqlens(seqlengths, inputArr.device)
-    ws, wp, wn = _sorf_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
+    ws, wp, wn = _conv_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_conv1d_fgen_{s}")(
         x, o, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
         inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], chiArr.shape[0],
@@ -326,7 +332,7 @@ def hipConvGrad(inputArr, outputArr, radem, chiArr, seqlengths, gradArr, sigma, 
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
     host, dev = _seqlens(seqlengths, inputArr.device)
-    ws, wp, wn = _sorf_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
+    ws, wp, wn = _conv_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_conv_grad_{s}")(
         x, o, g, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
         inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], gradArr.shape[0],
@@ -343,7 +349,7 @@ def hipConv1dMaxpool(inputArr, outputArr, radem, chiArr, seqlengths, convWidth):
     r = _radem3(radem)
     c = _dev(chiArr, "chiArr", inputArr.dtype, 1)
     host, dev = _seqlens(seqlengths, inputArr.device)
-    ws, wp, wn = _sorf_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
+    ws, wp, wn = _conv_ws(radem, int(convWidth) * inputArr.shape[2], inputArr)
     return _lib.check(getattr(_LIB, f"xgpr_conv1d_maxpool_{s}")(
         x, o, r, c, C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr()), inputArr.shape[0],
         inputArr.shape[1], inputArr.shape[2], outputArr.shape[0], outputArr.shape[1], chiArr.shape[0],
