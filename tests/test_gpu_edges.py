@@ -108,6 +108,44 @@ def test_conv_ragged_and_single_kmer(oracle, L, C, cw):
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("n,L", [(64, 40), (300, 64), (1500, 33)])
+def test_conv_longest_first_order_changes_nothing(oracle, monkeypatch, n, L):
+    """With room in the workspace (xgpr_conv_workspace_bytes) a convolution launch processes its longest sequences
+    first; with the smaller workspace it runs in the caller's order.  Features, max-pool features and gradients must
+    be bit-identical between the two, and equal to the oracle's."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(n + L)
+    C, cw, rffs = 5, 7, 2048
+    radem, chi = orc.draw_sorf_params(rffs, cw * C, 11, conv=True)
+    x = rng.standard_normal((n, L, C)).astype(np.float32)
+    sl = rng.integers(cw, L + 1, size=n).astype(np.int32)
+    sl[: n // 4] = L                                    # many ties, the longest first in the caller's order too
+    sl[-3:] = cw
+
+    def run_all():
+        out = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+        ext.hipConv1dFGen(dev(x), out, dev(radem), dev(chi), sl, cw, 1)
+        o2 = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+        g2 = torch.zeros((n, rffs, 1), dtype=torch.float64, device=DEV)
+        ext.hipConvGrad(dev(x), o2, dev(radem), dev(chi), sl, g2, 0.7, cw, 2)
+        F = rffs // 2
+        P = orc.padded_dims(cw * C)
+        radem_m = np.random.default_rng(3).choice(np.asarray([-1, 1], np.int8), size=(3, 1, -(-F // P) * P))
+        mp = torch.zeros((n, F), dtype=torch.float32, device=DEV)
+        ext.hipConv1dMaxpool(dev(x), mp, dev(radem_m), dev(np.ascontiguousarray(chi[:F])), sl, cw)
+        return out, o2, g2, mp
+
+    ordered = run_all()
+    monkeypatch.setattr(ext, "_conv_ws", ext._sorf_ws)  # the smaller workspace: no room for the order
+    plain = run_all()
+    for a, b in zip(ordered, plain):
+        assert torch.equal(a, b)
+    ref = np.zeros((n, rffs))
+    oracle.cpuConv1dFGen(x, ref, radem, chi, sl, cw, 1)
+    assert np.abs(ordered[0].cpu().numpy() - ref).max() <= 4e-7 * np.sqrt(2.0 / rffs) * (L - cw + 1)
+
+
 def test_fused_matvec_small_n_and_odd_tiles(oracle):
     """fewer datapoints than slots, F not a multiple of 1024 (partial last tile), nb = 3 and nb = 5."""
     from oracle import oracle as orc
