@@ -1,0 +1,26 @@
+"""The collective path on the one GPU of the test box: the driver's launch line with ONE rank whose collectives go
+through the backend (XGPR_DIST_FORCE=1) -- RCCL communicator set up on the device, all-reduce and barrier issued for
+real.  What N ranks add to this (the exchange over xGMI) only the driver's multi-GPU run can show."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_one_rank_through_rccl():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"XGPR_DIST_FORCE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-check", "--rows", "1000"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["backend"] == "nccl" and out["world_size"] == 1 and out["n_ranks_seen"] == 1
+    assert out["allreduce_w_us_back_to_back"] > 0 and out["shard_rows_per_rank"] == [1000.0]
