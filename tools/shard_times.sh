@@ -10,7 +10,7 @@ d=json.loads(open('gpurun_out/r2/shard_$rows.json').read().strip().splitlines()[
 print($rows, 'ms/step %.3f kernel %.3f build %.3f s' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['precond_build']['seconds']))
 "
 done
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r2/nccl1.json 2> gpurun_out/r2/nccl1.err
+XGPR_DIST_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r2/nccl1.json 2> gpurun_out/r2/nccl1.err
 python3 -c "
 import json
 d=json.loads(open('gpurun_out/r2/nccl1.json').read().strip().splitlines()[-1])
