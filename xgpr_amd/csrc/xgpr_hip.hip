@@ -230,8 +230,8 @@ int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefac
     const int nb = (int)(M < PRE_BLOCKS ? M : PRE_BLOCKS);
     hipLaunchKernelGGL(precond_utr_kernel, dim3(nb), dim3(256), 0, st, u, r, part, M, rank);
     HIP_TRY(hipGetLastError(), "precond_utr_kernel launch");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((rank + 63) / 64)), dim3(256), 0, st, part, t, rank, (long)nb);
-    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    hipLaunchKernelGGL(reduce_slabs_short_kernel, dim3((unsigned)((rank + 15) / 16)), dim3(256), 0, st, part, t, rank, (long)nb);
+    HIP_TRY(hipGetLastError(), "reduce_slabs_short_kernel launch");
     hipLaunchKernelGGL(precond_uz_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, u, t, inv_eig, prefactor, r, z,
                        M, rank);
     HIP_TRY(hipGetLastError(), "precond_uz_kernel launch");
