@@ -21,3 +21,11 @@ for rep in range(2):
     (mean, var), t = T(lambda: model.predict(xt, get_var=True)); print(f"predict 50000 rows with variance {t:.3f} s")
     mean2, t = T(lambda: model.predict(xt, get_var=False)); print(f"predict 50000 rows mean only {t:.3f} s")
 _, t = T(lambda: model.exact_nmll(np.log([0.1, 1.0]), data)) if False else (None, 0)
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    model.fit(data, preconditioner=pre, tol=1e-6)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(25)

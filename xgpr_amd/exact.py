@@ -61,7 +61,10 @@ def calc_variance_exact(kernel, dataset, variance_rffs):
         z_trans_z += xfeatures[:, :variance_rffs].T @ xfeatures[:, :variance_rffs]
     comm.all_reduce_(z_trans_z)
     z_trans_z.diagonal().add_(float(kernel.get_lambda()) ** 2)
-    return torch.linalg.pinv(z_trans_z)
+    # the matrix is symmetric positive definite (Gram block + lambda^2): the pseudo-inverse through the symmetric
+    # eigendecomposition (same cut-off rule as the SVD form the reference calls) -- rocSOLVER's Jacobi SVD of a
+    # 512 x 512 matrix takes 74 ms, its syevd 11
+    return torch.linalg.pinv(0.5 * (z_trans_z + z_trans_z.T), hermitian=True)
 
 
 def predict_mean(kernel, weights, input_x, trainy_mean, trainy_std, sequence_lengths=None, chunk_size=2000):
