@@ -25,7 +25,10 @@ if "--profile" in sys.argv:
     import cProfile, pstats
     pr = cProfile.Profile()
     pr.enable()
-    model.fit(data, preconditioner=pre, tol=1e-6)
+    if "--auto" in sys.argv:
+        model.fit(data, tol=1e-6)
+    else:
+        model.fit(data, preconditioner=pre, tol=1e-6)
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(25)

@@ -227,6 +227,15 @@ def _tall_svd(b_mat):
     return u_mat, s_mat
 
 
+def _tall_svals(b_mat):
+    """Singular values of b_mat [M, rank], descending -- what the rank check needs of the thin SVD: the eigenvalues of
+    the Gram matrix alone (no eigenvectors, no back-transformation: roughly half the symmetric eigensolver's work)."""
+    evals = torch.linalg.eigvalsh(b_mat.T @ b_mat)
+    if float(evals[0].item()) * GRAM_COND_LIMIT > float(evals[-1].item()) > 0:
+        return torch.sqrt(evals.flip(0))
+    return torch.linalg.svdvals(b_mat)
+
+
 def _orthonormal_basis(a_mat):
     """Q of the thin QR of a_mat [M, rank] up to column signs (rand_nys_constructors.py:187): two rounds of
     Cholesky QR, checked, with Householder QR as the fallback."""
@@ -304,8 +313,7 @@ def srht_ratio_check(dataset, rank, kernel, random_state, verbose=False, sample_
     dataset.comm.all_reduce_(acc_results)
     c_mat = compressor.transform_x(acc_results)
     acc_results = _inv_sqrt_apply(acc_results.T, c_mat)
-    _, s_mat = _tall_svd(acc_results)
-    return s_mat ** 2
+    return _tall_svals(acc_results) ** 2
 
 
 def check_rank_ratio(kernel, dataset, sample_frac=0.1, max_rank=512, random_seed=123, verbose=False):
