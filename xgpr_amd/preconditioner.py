@@ -66,7 +66,7 @@ def _srht_pass_rows(dataset, kernel, compressor, acc_results, z_trans_y, from_ca
     z_trans_y None: classification, no z^T y.  Returns y^T y (device scalar)."""
     icpt, scale = kernel.row_cache_params()
     rank, m = acc_results.shape
-    lds = (rank + 63) // 64 * 64
+    lds = (rank + 127) // 128 * 128          # whole 128-row tiles: the LDS-staged contraction kernel
     dev = acc_results.device
     y_trans_y = torch.zeros(1, dtype=torch.float64, device=dev)
     zty_chunk = None if z_trans_y is None else torch.empty_like(z_trans_y)
@@ -93,7 +93,7 @@ def _gauss_pass_rows(dataset, kernel, q_mat, acc_results, from_cache):
     """single_pass_gauss (rand_nys_constructors.py:18-36): acc[M, rank] += Z^T (Z Q) over float32 rows."""
     icpt, scale = kernel.row_cache_params()
     m, rank = acc_results.shape
-    ldq = (rank + 63) // 64 * 64
+    ldq = (rank + 127) // 128 * 128
     dev = acc_results.device
     qpad = torch.zeros((m, ldq), dtype=torch.float64, device=dev)
     qpad[:, :rank] = q_mat
