@@ -164,6 +164,30 @@ def test_fused_matvec_small_n_and_odd_tiles(oracle):
         assert np.abs(w.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), (n, d, rffs)
 
 
+@pytest.mark.parametrize("d,m", [(90, 4096), (1001, 8192), (130, 2050)])
+def test_scaled_shard_rows_padded_to_16_bytes(d, m):
+    """Input widths that are not a multiple of four: the shard's scaled copy gets zero columns up to the next multiple
+    (what the transform's own zero padding would hold), so the three-wave fused matvec (16-byte-aligned rows) serves
+    them too; Z^T (Z v) through it equals the product over the feature operator's float64 output on the unpadded rows."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    rng = np.random.default_rng(d)
+    n = 3000
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    ds = build_regression_dataset(x, rng.standard_normal(n), chunk_size=1000, device=DEV)
+    kern = make_kernel("RBF", (n, d), m, 123, DEV, {})
+    kern.set_hyperparams(np.array([0.3, 0.8]), logspace=False)
+    xs = ds.scaled_x(kern.hyperparams[1])
+    assert xs.shape[1] % 4 == 0 and xs.shape[1] - d < 4 and float(xs[:, d:].abs().max()) == 0.0
+    v = torch.randn(m, dtype=torch.float64, device=DEV)
+    w = torch.empty_like(v)
+    ws = torch.empty(kern.workspace_bytes(), dtype=torch.uint8, device=DEV)
+    kern.ztz_matvec(xs, v, w, ws)
+    z = kern.transform_x(torch.from_numpy(x).to(DEV))
+    ref = z.T @ (z @ v)
+    assert float((w - ref).abs().max()) <= 1e-7 * float(ref.abs().max())
+
+
 def test_offline_dataset_on_device(tmp_path):
     """.npy chunk files -> pinned host buffers -> HBM shard (loader thread + copy stream); a fit on it equals
     the fit on the in-memory dataset."""

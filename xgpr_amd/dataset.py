@@ -124,10 +124,18 @@ class DeviceDataset:
     def scaled_x(self, sigma):
         """The whole shard pre-multiplied by sigma (what ``transform_x`` does to each chunk
         copy, sorf_kernel_baseclass.py:117), cached per sigma for the fused kernels."""
-        from .kernels import scale_input
+        from .kernels import scale_input, padded_dims
         key = float(sigma)
         if key not in self._scaled:
-            self._scaled = {key: scale_input(self._xdata, key)}
+            xs = scale_input(self._xdata, key)
+            # rows a multiple of four floats (zero columns appended, which is what the transform's own zero padding up
+            # to the next power of two would have put there): 16-byte-aligned rows are what the three-wave fused matvec
+            # fetches by LDS-DMA, so every input width gets that kernel
+            if xs.dim() == 2 and xs.shape[1] % 4 != 0 and (xs.shape[1] + 3) // 4 * 4 <= padded_dims(xs.shape[1]):
+                xp = torch.zeros((xs.shape[0], (xs.shape[1] + 3) // 4 * 4), dtype=xs.dtype, device=xs.device)
+                xp[:, :xs.shape[1]] = xs
+                xs = xp
+            self._scaled = {key: xs}
         return self._scaled[key]
 
 
