@@ -180,6 +180,47 @@ def cpu_baseline(args, budget_s):
     }
 
 
+# loss (relative residual) of the preconditioned CG solve after `steps` iterations: (rows, dim, rffs, rank, steps) -> value
+EXPECTED_FINAL_LOSS = {(1_000_000, 1024, 8192, 512, 20): 0.0130151070155}
+
+
+def valu_only_probe(kern, ds, kern_ms, device):
+    """Times the fused matvec of this rank's shard through the VALU-only timing probe (xgpr_amd/build.py PROBE_LIB: the
+    kernel's vector instruction stream with LDS traffic, barrier and prefetch compiled out; results meaningless, never
+    used).  Returns {"ms", "frac"} or None when the probe library has not been built."""
+    import ctypes as C
+    path = os.path.join(ROOT, "xgpr_amd", "libxgpr_hip_valuonly_probe.so")
+    if not os.path.exists(path):
+        return None
+    fn = C.CDLL(path).xgpr_ztz_matvec_f32
+    vp, l, i, sz = C.c_void_p, C.c_long, C.c_int, C.c_size_t
+    fn.argtypes = [vp, vp, vp, vp, vp, l, l, l, l, l, i, vp, sz, vp]
+    fn.restype = C.c_int
+    xs = ds.scaled_x(1.0)
+    mm = kern.num_rffs
+    v = torch.randn(mm, dtype=torch.float64, device=device)
+    w = torch.empty_like(v)
+    ws = torch.empty(kern.workspace_bytes(), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call():
+        rc = fn(xs.data_ptr(), kern.radem_diag.data_ptr(), kern.chi_arr.data_ptr(), v.data_ptr(), w.data_ptr(), xs.shape[0],
+                xs.shape[1], mm, kern.num_freqs, kern.radem_diag.shape[2], int(kern.fit_intercept), ws.data_ptr(),
+                ws.numel(), stream)
+        if rc != 0:
+            raise RuntimeError("VALU-only probe launch failed")
+    for _ in range(2):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        call()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return {"ms": ms, "frac": ms / kern_ms, "source": "live: libxgpr_hip_valuonly_probe.so (timing-only build, -DXGPR_ABL_VALUONLY)"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -298,6 +339,13 @@ def main():
     comm.barrier()
     t1 = time.perf_counter()
     assert niter == args.steps
+    # the timed iterations are a real solve: for the default problem the loss after `steps` iterations is a stored
+    # value (measured on MI355X; the synthetic data, preconditioner and iterates are deterministic up to the summation
+    # order over ranks and the eigensolver's last digits)
+    key = (args.rows, args.dim, args.rffs, args.rank_precond, args.steps)
+    if key in EXPECTED_FINAL_LOSS and abs(losses[-1] / EXPECTED_FINAL_LOSS[key] - 1.0) > 1e-6:
+        raise RuntimeError(f"final loss {losses[-1]!r} differs from the stored {EXPECTED_FINAL_LOSS[key]!r}: the timed "
+                           "iterations did not do the work they claim")
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if comm.through_backend:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
@@ -432,22 +480,31 @@ def main():
                 traffic = pm["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        # the resource this kernel is actually bound by: vector-instruction issue.  Instructions per wave tile
-        # (1024 frequencies of one datapoint) from the SQ counters of this kernel (profiles/r2_fused_pmc_sq.json,
-        # cfg3 shape) x the tiles of this launch / the live kernel time, against one VALU issue per SIMD every 4
-        # cycles at the 2.4 GHz peak clock
+        # the resource this kernel is actually bound by: the vector pipe.  Three readings, each labelled:
+        #  issue_slots -- vector instructions per wave tile (static count of the loop's hot path from the disassembly,
+        #                 tools/count_loop_insts.py -> profiles/r3_ztz3_inst_table.json) x tiles / live kernel time, against
+        #                 one wave-instruction per TWO cycles per SIMD at 2.4 GHz (the rate of v_add_f32; most of this
+        #                 kernel's instructions -- packed, DPP, float64, conversions -- occupy the pipe for four cycles,
+        #                 cos/sin for eight, so this reading cannot reach 1)
+        #  priced      -- sum over instruction classes of count x measured issue cost at three waves per SIMD
+        #                 (tools/valu_cost.hip -> profiles/r3_valu_cost.json), i.e. the time the vector pipe is occupied,
+        #                 over the live kernel time
+        #  valu_only   -- LIVE: the same launch through the VALU-only timing probe (xgpr_amd/build.py PROBE_LIB: same
+        #                 instruction stream, LDS traffic / barrier / prefetch compiled out), over the live kernel time
         vector_pipe = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r2_fused_pmc_sq.json")))["wave_ztz_kernel"]["derived"]
+            tab = json.load(open(os.path.join(ROOT, "profiles", "r3_ztz3_inst_table.json")))
             if (d, m) == (1024, 8192):
                 tiles = n_local * ((m // 2 + 1023) // 1024)
-                peak_inst = 256 * 4 * 2.4e9 / 4
-                inst_s = sq["valu_insts_per_tile"] * tiles / (kern_ms * 1e-3)
-                vector_pipe = {"valu_insts_per_tile": sq["valu_insts_per_tile"], "tiles_per_launch": tiles,
-                               "achieved": inst_s / 1e9, "peak": peak_inst / 1e9, "unit": "G wave-instructions/s",
-                               "frac": inst_s / peak_inst,
-                               "measured_clock_GHz": sq["clock_GHz"],
-                               "valu_busy_at_measured_clock": sq["valu_active_frac_of_simd_cycles"]}
+                peak_inst = 256 * 4 * 2.4e9 / 2
+                inst_s = tab["valu_instructions"] * tiles / (kern_ms * 1e-3)
+                pipe_ms = tab["priced_vector_ns_per_tile_per_simd"] * tiles / 1024 * 1e-6
+                vector_pipe = {"valu_insts_per_tile": tab["valu_instructions"], "tiles_per_launch": tiles,
+                               "issue_slots": {"achieved": inst_s / 1e9, "peak": peak_inst / 1e9, "unit": "G wave-instructions/s",
+                                               "frac": inst_s / peak_inst},
+                               "priced": {"pipe_ms": pipe_ms, "frac": pipe_ms / kern_ms,
+                                          "source": "profiles/r3_ztz3_inst_table.json x profiles/r3_valu_cost.json (stored)"},
+                               "valu_only": valu_only_probe(kern, ds, kern_ms, device)}
         except (OSError, KeyError, ValueError):
             pass
         alg_bytes = 4.0 * d * n_local                   # 4*d bytes per row, X read once
@@ -476,9 +533,9 @@ def main():
                          "command; stored, not re-measured in this run)" if traffic is not None else None,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
                          "vector_pipe": vector_pipe,
-                         "note": "HBM traffic of this kernel is only the X read; the binding resources are the vector pipe "
-                                 "(butterflies + sincos) and LDS-exchange latency at 3 waves/SIMD: "
-                                 "profiles/r2_fused_pmc_sq.json, DESIGN.md section 3"},
+                         "note": "HBM traffic of this kernel is only the X read; the binding resource is the vector pipe "
+                                 "(butterflies, cos/sin, float64 dot + rank-1 update) at 3 waves/SIMD: vector_pipe, "
+                                 "profiles/r3_fused_pmc_sq.json, DESIGN.md section 3"},
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},

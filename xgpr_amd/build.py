@@ -14,6 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "xgpr_hip.hip")
 HDR = os.path.join(HERE, "..", "include", "xgpr_hip.h")
 LIB = os.path.join(HERE, "libxgpr_hip.so")
+# Roofline probe, NOT a product library: the same translation unit with -DXGPR_ABL_VALUONLY, in which the fused CG
+# matvec keeps its vector instruction stream but has its LDS traffic, workgroup barrier and prefetch DMA compiled
+# out (its results are meaningless).  bench.py times it beside the real kernel: the ratio is how much of the kernel's
+# time its own vector instructions need at the kernel's occupancy.  Nothing under xgpr_amd/ loads it.
+PROBE_LIB = os.path.join(HERE, "libxgpr_hip_valuonly_probe.so")
 
 # -ffp-contract=off: the butterflies / Rademacher multiplies must round like the reference's
 # scalar code (see the header comment of csrc/xgpr_hip.hip).
@@ -40,6 +45,16 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in sources())
 
 
+def build_probe(force=False):
+    """Compile the VALU-only timing probe (see PROBE_LIB) if missing or older than its sources."""
+    if not force and os.path.exists(PROBE_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(PROBE_LIB) for p in sources()):
+        return PROBE_LIB
+    res = subprocess.run([hipcc_path()] + FLAGS + ["-DXGPR_ABL_VALUONLY", SRC, "-o", PROBE_LIB], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed (probe):\n" + res.stdout + res.stderr)
+    return PROBE_LIB
+
+
 def build_extension(force=False, verbose=False):
     """Compile csrc/xgpr_hip.hip -> libxgpr_hip.so if missing or older than its sources."""
     if not force and not is_stale():
@@ -55,3 +70,5 @@ def build_extension(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build_extension(force="--force" in sys.argv, verbose=True))
+    if "--probe" in sys.argv:
+        print(build_probe(force="--force" in sys.argv))
