@@ -10,6 +10,8 @@ from xgpr_amd.kernels import make_kernel
 from xgpr_amd import _lib
 
 ROUNDS, CALLS = 7, 5
+ZTY = "--zty" in sys.argv            # time xgpr_zty_f32 (z^T y) instead of the matvec
+if ZTY: sys.argv.remove("--zty")
 n, d, m = (int(t) for t in sys.argv[1].split())
 paths = [(_lib.LIB_PATH if p == "current" else p if os.path.exists(p) else f"tools/ablate/lib_{p}.so") for p in sys.argv[2:]]
 dev = "cuda"
@@ -17,16 +19,16 @@ g = torch.Generator(device=dev).manual_seed(1)
 xs = torch.randn(n, d, device=dev, generator=g) / d ** 0.5
 kern = make_kernel("Matern", (n, d), m, 123, dev, {"matern_nu": 2.5})
 kern.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
-v = torch.randn(m, dtype=torch.float64, device=dev, generator=g)
+v = torch.randn(n if ZTY else m, dtype=torch.float64, device=dev, generator=g)
 ws = torch.empty(kern.workspace_bytes(), dtype=torch.uint8, device=dev)
 radem, chi = kern.radem_diag, kern.chi_arr
 vp, l, i, sz = C.c_void_p, C.c_long, C.c_int, C.c_size_t
 libs = []
 for p in paths:
     lib = C.CDLL(p)
-    fn = lib.xgpr_ztz_matvec_f32
+    fn = lib.xgpr_zty_f32 if ZTY else lib.xgpr_ztz_matvec_f32
     fn.argtypes = [vp, vp, vp, vp, vp, l, l, l, l, l, i, vp, sz, vp]; fn.restype = C.c_int
-    libs.append((p, fn, torch.empty_like(v)))
+    libs.append((p, fn, torch.empty(m, dtype=torch.float64, device=dev)))
 def call(fn, w):
     rc = fn(xs.data_ptr(), radem.data_ptr(), chi.data_ptr(), v.data_ptr(), w.data_ptr(), n, d, m, kern.num_freqs,
             radem.shape[2], int(kern.fit_intercept), ws.data_ptr(), ws.numel(), 0)
