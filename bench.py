@@ -189,6 +189,7 @@ def valu_only_probe(kern, ds, kern_ms, device):
     kernel's vector instruction stream with LDS traffic, barrier and prefetch compiled out; results meaningless, never
     used).  Returns {"ms", "frac"} or None when the probe library has not been built."""
     import ctypes as C
+    import torch
     path = os.path.join(ROOT, "xgpr_amd", "libxgpr_hip_valuonly_probe.so")
     if not os.path.exists(path):
         return None

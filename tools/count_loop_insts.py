@@ -16,7 +16,7 @@ with tempfile.TemporaryDirectory() as td:
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-S", "--cuda-device-only",
                     os.path.join(ROOT, "xgpr_amd/csrc/xgpr_hip.hip"), "-o", asm], check=True, capture_output=True)
     lines = open(asm).read().split("\n")
-name = f"ztz3_kernelILi{lg}E"
+name = f"ztz3_kernelILi{lg}ELi0E"      # MODE 0 = Z3_MATVEC
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and name in l and ":" in l.split(";")[0])
 end = next(i for i in range(start, len(lines)) if ".amdhsa_kernel" in lines[i])
 body = lines[start:end]
@@ -39,7 +39,7 @@ costs = json.load(open(cost_file))
 alias = {"v_sub_f32": "v_add_f32", "v_fmac_f32": "v_fma_f32", "v_fma_f64": "v_fmac_f64", "v_mul_f64": "v_fmac_f64", "v_lshlrev_b32": "v_bitop3_b32",
          "v_and_b32": "v_add_u32", "v_xor_b32": "v_add_u32", "v_or_b32": "v_add_u32", "v_cndmask_b32": "v_cndmask_b32_e64", "v_mov_b64": "v_add_f64",
          "v_permlane16_swap_b32": "v_permlane32_swap_b32", "v_lshl_add_u32": "v_bitop3_b32", "v_add3_u32": "v_bitop3_b32", "v_readlane_b32": "v_mov_b32",
-         "v_readfirstlane_b32": "v_mov_b32", "v_cmp_gt_i32": "v_cndmask_b32_e64", "v_cmp_ngt_f32": "v_cndmask_b32_e64", "v_cmp_lt_f32": "v_cndmask_b32_e64",
+         "v_readfirstlane_b32": "v_mov_b32", "v_cmp_gt_i32": "v_cndmask_b32_e64", "v_cmp_ne_u32": "v_cndmask_b32_e64", "v_cmp_eq_u32": "v_cndmask_b32_e64", "v_cmp_ngt_f32": "v_cndmask_b32_e64", "v_cmp_lt_f32": "v_cndmask_b32_e64",
          "v_lshl_add_u64": "v_add_f64", "v_ashrrev_i32": "v_bitop3_b32"}
 table, priced, unpriced = [], 0.0, []
 for op, c in sorted(counts.items(), key=lambda kv: -kv[1]):
@@ -50,7 +50,7 @@ for op, c in sorted(counts.items(), key=lambda kv: -kv[1]):
     if kind == "valu" and ns is None: unpriced.append(op)
     if ns: priced += ns * c
     table.append({"op": op, "count": c, "class": kind, "ns_each_W3": ns, "ns_total": None if ns is None else round(ns * c, 1)})
-res = {"kernel": f"ztz3_kernel<{lg}>", "what": "instructions executed per wave per datapoint tile (1024 frequencies) on the hot path of the main loop",
+res = {"kernel": f"ztz3_kernel<{lg}, Z3_MATVEC>", "what": "instructions executed per wave per datapoint tile (1024 frequencies) on the hot path of the main loop",
        "valu_instructions": sum(c for o, c in counts.items() if o.startswith("v_")),
        "lds_instructions": sum(c for o, c in counts.items() if o.startswith("ds_")),
        "other_instructions": sum(c for o, c in counts.items() if not o.startswith(("v_", "ds_"))),

@@ -1,82 +1,67 @@
-"""Host-side model of the fused matvec's exchange ("x4": ds_write_addtid_b32 chunks + wide reads).
-Checks (1) that the two exchanges move tile element t between layout R and layout C, (2) that every LDS access
-pattern of the kernel is conflict-free under the per-instruction lane groups of MI355X_MICROARCH.md (LDS).
+"""Host-side model of the exchange between the two register layouts of the wave-level FHT ("x4": ds_write_addtid_b32
+chunks + wide reads, xgpr_amd/csrc/wave_sorf.inc).  Checks (1) that the two exchanges move tile element t between
+layout R (lane = t >> 4, register = t & 15) and layout C (lane = t & 63, register = t >> 6), (2) that every LDS access
+pattern is conflict-free under the per-instruction lane groups of MI355X_MICROARCH.md (LDS).
     python tools/x4_layout_check.py"""
-import itertools
-
-def lane_R(t):  # register j = t & 15
-    b, r = (t >> 4) & 3, t >> 6
-    return (r & 3) | (b << 2) | ((r >> 2) << 4)
-def lane_C(t):  # register r = t >> 6
-    b, j = (t >> 4) & 3, t & 15
-    return b | (j << 2)
-A = lambda j: 64 * (4 * (j & 3) + (j >> 2)) + 16 * (j & 3)          # R -> C chunk base of register j (dwords)
-B = lambda r: 64 * (2 * (r & 7) + (r >> 3)) + 4 * (r & 7)            # C -> R chunk base of register r
-X4_DWORDS = 1072
-
 G128 = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
 G128 += [[l + 32 for l in g] for g in G128]
 G32 = [list(range(32)), list(range(32, 64))]
+X4_DWORDS = 1056
+A = lambda j: 66 * j                                             # R -> C: chunk of register j (dwords)
+B = lambda r: 64 * (4 * (r & 3) + (r >> 2)) + 4 * (r & 3)         # C -> R: chunk of register r
 
-def conflicts_b128(addr_of_lane):      # dword addresses (16-byte aligned), 64 banks
+def conflicts_b128(addr):       # dword addresses (16-byte aligned), 64 banks, four groups of 16 lanes
     worst = 1
     for grp in G128:
         per_bank = {}
         for l in grp:
-            a = addr_of_lane(l)
+            a = addr(l)
+            assert a % 4 == 0
             for k in range(4):
                 per_bank.setdefault((a + k) % 64, set()).add(a + k)
         worst = max(worst, max(len(s) for s in per_bank.values()))
     return worst
-def conflicts_b32(addr_of_lane):       # 32 banks, two groups of 32 lanes
+def conflicts_b32(addr):        # 32 banks, two groups of 32 lanes
     worst = 1
     for grp in G32:
         per_bank = {}
         for l in grp:
-            a = addr_of_lane(l)
+            a = addr(l)
             per_bank.setdefault(a % 32, set()).add(a)
         worst = max(worst, max(len(s) for s in per_bank.values()))
     return worst
 
-# ---- (1) R -> C
+# R -> C: register j of lane p = t >> 4 stored at A(j) + p; C lane e = 16 b + j reads r = 0..15 at A(j) + b + 4 r
 buf = {}
 for t in range(1024):
-    a = A(t & 15) + lane_R(t); assert a not in buf and a < X4_DWORDS; buf[a] = t
-for lc in range(64):
-    b, j = lc & 3, lc >> 2
-    for g in range(4):
-        for k in range(4):
-            t = buf[A(j) + 4 * b + 16 * g + k]
-            assert lane_C(t) == lc and (t >> 6) == 4 * g + k, (lc, g, k, t)
-for g in range(4):
-    assert conflicts_b128(lambda l: A(l >> 2) + 4 * (l & 3) + 16 * g) == 1
-# ---- (1) C -> R
+    a = A(t & 15) + (t >> 4); assert a not in buf and a < X4_DWORDS; buf[a] = t
+for e in range(64):
+    b, j = e >> 4, e & 15
+    for r in range(16):
+        t = buf[A(j) + b + 4 * r]; assert (t & 63) == e and (t >> 6) == r
+for r in range(16):
+    assert conflicts_b32(lambda l: A(l & 15) + (l >> 4) + 4 * r) == 1
+# C -> R: register r of lane e = t & 63 stored at B(r) + e; R lane p = b + 4 r reads j = 4 g .. 4 g + 3 at B(r) + 16 b + 4 g
 buf = {}
 for t in range(1024):
-    a = B(t >> 6) + lane_C(t); assert a not in buf and a < X4_DWORDS; buf[a] = t
-for lr in range(64):
-    b, r = (lr >> 2) & 3, (lr & 3) | ((lr >> 4) << 2)
+    a = B(t >> 6) + (t & 63); assert a not in buf and a < X4_DWORDS; buf[a] = t
+for p in range(64):
+    b, r = p & 3, p >> 2
     for j in range(16):
-        t = buf[B(r) + b + 4 * j]
-        assert lane_R(t) == lr and (t & 15) == j
-for j in range(16):
-    assert conflicts_b32(lambda l: B((l & 3) | ((l >> 4) << 2)) + ((l >> 2) & 3) + 4 * j) == 1
-# ---- x image: natural rows of 16 floats, 16-byte group g of row p at slot g ^ ((p >> 2) & 3); R lane l reads row
-# p(l) = b + 4 r (mod P / 16)
-def prow(l):
-    b, r = (l >> 2) & 3, (l & 3) | ((l >> 4) << 2)
-    return b + 4 * r
-assert sorted(prow(l) for l in range(64)) == list(range(64))
-for t in range(1024):
-    assert prow(lane_R(t)) == t >> 4
-for P in (128, 256, 512, 1024):
+        t = buf[B(r) + 16 * b + j]; assert (t >> 4) == p and (t & 15) == j
+for g in range(4):
+    assert conflicts_b128(lambda l: B(l >> 2) + 16 * (l & 3) + 4 * g) == 1
+# first exchange of a tile with N = P / 64 distinct input registers: R lane p reads chunk (p >> 2) mod N
+for N in (2, 4, 8):
     for g in range(4):
-        def addr(l):
-            p = prow(l) & (P // 16 - 1)
-            return 16 * p + 4 * (g ^ ((p >> 2) & 3))
-        assert conflicts_b128(addr) == 1, P
-# ---- chi image: one 64-byte row per C lane, group g at slot g ^ row_swz(lane)
+        assert conflicts_b128(lambda l: B((l >> 2) & (N - 1)) + 16 * (l & 3) + 4 * g) == 1, N
+# images the fused matvec keeps beside it, 64-byte rows read with four ds_read_b128: chi (one row per lane, group g at slot
+# g ^ row_swz(lane)) and the datapoint's row (lane l reads row l mod (P / 16), group g at slot g ^ x_swz(row))
 row_swz = lambda p: ((p >> 1) & 3) ^ ((p >> 4) & 3)
+x_swz = lambda p: (p >> 2) & 3
 for g in range(4):
     assert conflicts_b128(lambda l: 16 * l + 4 * (g ^ row_swz(l))) == 1
+for P in (128, 256, 512, 1024):
+    for g in range(4):
+        assert conflicts_b128(lambda l: 16 * (l & (P // 16 - 1)) + 4 * (g ^ x_swz(l & (P // 16 - 1)))) == 1, P
 print("x4 layout: exchanges consistent, all access patterns conflict-free; buffer", X4_DWORDS * 4, "bytes per wave")
