@@ -180,6 +180,45 @@ def cpu_baseline(args, budget_s):
     }
 
 
+def conv_featgen_probe(device, nseq=8192):
+    """The convolution feature operator (cudaConv1dFGen's drop-in) at BASELINE configs[3]'s shape: one-hot protein-like
+    sequences, L <= 512, 21 channels, conv_width 9, 16384 RFFs, 'sqrt' averaging; 8192 sequences per call (the window the
+    feature cache is built in).  The kernel is vector-pipe bound: `priced` is count x measured issue cost of its k-mer
+    loop (profiles/r3_conv_inst_table.json, tools/count_loop_insts.py conv 8) over the measured time."""
+    import torch
+    from xgpr_amd.kernels import make_kernel
+    L, C, m, w = 512, 21, 16384, 9
+    g = torch.Generator(device=device).manual_seed(3)
+    x = torch.nn.functional.one_hot(torch.randint(0, C, (nseq, L), device=device, generator=g), C).to(torch.float32)
+    sl = torch.randint(64, L + 1, (nseq,), generator=torch.Generator().manual_seed(5)).numpy().astype(np.int32)
+    kern = make_kernel("Conv1dRBF", (nseq, L, C), m, 123, device, {"conv_width": w, "averaging": "sqrt"})
+    kern.set_hyperparams(np.array([1.0, 0.8]), logspace=False)
+    kern.transform_x(x, sl)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        z = kern.transform_x(x, sl)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del z
+    kmers = int((sl.astype(np.int64) - w + 1).sum())
+    tiles = kmers * (m // 2 // 1024)                     # wave tiles (1024 frequencies of one k-mer)
+    out = {"workload": "BASELINE configs[3] shape: Conv1dRBF, %d sequences (L 64..512, 21 channels, conv_width 9), %d RFFs" % (nseq, m),
+           "ms": ms, "sequences_per_s": nseq / (ms * 1e-3), "kmers": kmers, "tile_transforms_per_s": tiles / (ms * 1e-3),
+           "note": "whole operator call (transform_x: scaling of the input copy, ordering kernel, feature kernel, float64 output)"}
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r3_conv_inst_table.json")))
+        pipe_ms = tab["priced_vector_ns_per_tile_per_simd"] * tiles / 1024 * 1e-6
+        out["vector_pipe"] = {"valu_insts_per_kmer_tile": tab["valu_instructions"],
+                              "priced": {"pipe_ms": pipe_ms, "frac": pipe_ms / ms,
+                                         "source": "profiles/r3_conv_inst_table.json x profiles/r3_valu_cost.json (stored)"}}
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
 # loss (relative residual) of the preconditioned CG solve after `steps` iterations: (rows, dim, rffs, rank, steps) -> value
 EXPECTED_FINAL_LOSS = {(1_000_000, 1024, 8192, 512, 20): 0.0130151070155}
 
@@ -467,6 +506,8 @@ def main():
     fg_ms = e0.elapsed_time(e1) / reps
     del zbuf
 
+    conv = conv_featgen_probe(device) if (comm.rank == 0 and args.gpus == 1) else None
+
     if comm.rank == 0:
         n_local = hi - lo
         # HBM bytes per launch of the dominant kernel from the PMC counters: a STORED measurement (separate
@@ -540,6 +581,7 @@ def main():
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},
+            "conv_featgen": conv,
             "cached_z_mode": cached,
             "distributed": {**dist_info,
                             "per_rank": [{"rank": i, "ms_per_step": v[0], "fused_kernel_ms": v[1],
