@@ -25,6 +25,7 @@ Besides the contract fields the JSON line carries
   precond_build -- the randomized-Nystrom build that precedes the timed steps: its dense work 2*N*rank*M
                    float64 flop over its wall time, against the FP64 matrix peak
   distributed   -- ranks the all-reduce summed over, per-rank step / kernel / all-reduce times
+  conv_featgen  -- the convolution feature operator at BASELINE configs[3]'s shape (8192 sequences per call)
   cpu_baseline  -- the CPU oracle (OpenMP port of the reference CPU algorithm) timed on this
                    box's host cores on a bounded row sample (rank 0, --gpus 1 only)
 """
@@ -185,6 +186,7 @@ def conv_featgen_probe(device, nseq=8192):
     sequences, L <= 512, 21 channels, conv_width 9, 16384 RFFs, 'sqrt' averaging; 8192 sequences per call (the window the
     feature cache is built in).  The kernel is vector-pipe bound: `priced` is count x measured issue cost of its k-mer
     loop (profiles/r3_conv_inst_table.json, tools/count_loop_insts.py conv 8) over the measured time."""
+    import numpy as np
     import torch
     from xgpr_amd.kernels import make_kernel
     L, C, m, w = 512, 21, 16384, 9

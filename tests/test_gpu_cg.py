@@ -106,6 +106,13 @@ def test_g8_reference_fixture_end_to_end():
     z = kern.transform_x(g["xtest"])
     preds = (z @ w).cpu().numpy() * ds.get_ystd() + ds.get_ymean()
     assert np.allclose(preds, g["preds"], rtol=1e-5, atol=1e-6)
+    # the fused predictor (float32 feature rows -> one-column projection on the matrix cores, no float64 Z) against
+    # the reference's predictions and against the materialised product, over ragged chunks
+    from xgpr_amd.exact import predict_mean
+    for chunk in (2000, 17):
+        pm = predict_mean(kern, w, g["xtest"], ds.get_ymean(), ds.get_ystd(), chunk_size=chunk).cpu().numpy()
+        assert np.allclose(pm, g["preds"], rtol=1e-5, atol=1e-6)
+        assert np.abs(pm - preds).max() <= 1e-12 * max(1.0, np.abs(preds).max())
 
 
 def test_conv_kernel_cg_matches_oracle(oracle):

@@ -192,3 +192,36 @@ def test_approximate_nmll_within_one_percent_of_exact_at_moderate_size():
             for c in (False, True)]
     assert abs(vals[0] - vals[1]) <= 1e-9 * abs(vals[0])
     assert 100 * abs(vals[0] - exact) / abs(exact) < 1.0
+
+
+def test_cfg3_full_size_matvec_is_the_sum_of_its_shards_and_reproducible():
+    """BASELINE configs[2] at its FULL size (N = 1e6, d = 1024, 8192 RFFs, Matern-5/2): the fused matvec over all rows
+    equals the sum of the matvecs of 8 contiguous shards (what the 8-GPU run adds up with its all-reduce) to float64
+    rounding, two launches return the same bits, and z^T y obeys the same additivity."""
+    from xgpr_amd.kernels import make_kernel
+    name, n, d, m, parms = _cfg("cfg3")
+    k = make_kernel(name, (n, d), m, 123, DEV, parms)
+    k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+    x = _data(n, d, seed=3)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(9)
+    v = torch.randn(m, dtype=torch.float64, device=DEV, generator=g)
+    y = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    ws = torch.empty(k.workspace_bytes(), dtype=torch.uint8, device=DEV)
+    full, again = torch.empty_like(v), torch.empty_like(v)
+    k.ztz_matvec(x, v, full, ws)
+    k.ztz_matvec(x, v, again, ws)
+    assert torch.equal(full, again)
+    assert bool(torch.isfinite(full).all())
+    parts, part = torch.zeros_like(v), torch.empty_like(v)
+    bounds = [(r * n) // 8 for r in range(9)]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        k.ztz_matvec(x[lo:hi], v, part, ws)
+        parts += part
+    assert float((full - parts).abs().max() / full.abs().max()) < 1e-12
+    zty, zty_parts = torch.empty_like(v), torch.zeros_like(v)
+    k.zty(x, y, zty, ws)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        k.zty(x[lo:hi], y[lo:hi], part, ws)
+        zty_parts += part
+    assert float((zty - zty_parts).abs().max() / zty.abs().max()) < 1e-12

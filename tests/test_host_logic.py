@@ -124,3 +124,45 @@ def test_offline_dataset_streams_npy_chunk_files(tmp_path):
         yif.append(str(tmp_path / f"yi{i}.npy"))
     cls = build_offline_np_dataset(xf, yif, chunk_size=64, device="cpu", task_type="classification")
     assert cls.get_n_classes() == 3 and cls.get_ndatapoints() == 131
+
+
+def test_inv_sqrt_apply_gates_the_cholesky_route_on_a_real_condition_estimate():
+    """preconditioner._inv_sqrt_apply: acc @ C^(-1/2) up to an orthogonal factor, so the thin SVD of the result must not
+    depend on the route.  A sketch with a ROTATED spectrum of condition 1e9 has an innocuous-looking Cholesky diagonal
+    (ratio^2 far below 1e6, what the gate used to test) and must NOT take the triangular route; a well-conditioned one
+    may.  Both are compared with the SVD form the reference calls (rand_nys_constructors.py:275-285)."""
+    import torch
+    from xgpr_amd import preconditioner as pc
+    gen = torch.Generator().manual_seed(5)
+    n, m = 96, 400
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=gen, dtype=torch.float64))
+    acc_t = torch.randn(m, n, generator=gen, dtype=torch.float64)
+
+    def reference(c_mat):
+        _, s1, v1 = torch.linalg.svd(c_mat, full_matrices=False)
+        return acc_t @ v1.T @ ((1 / torch.sqrt(s1))[:, None] * v1)
+
+    for cond, expect_chol in ((1e3, True), (1e9, False)):
+        lam = torch.logspace(0, -np.log10(cond), n, dtype=torch.float64)
+        c_mat = (q * lam[None, :]) @ q.T
+        c_mat = 0.5 * (c_mat + c_mat.T)
+        chol = torch.linalg.cholesky(c_mat)
+        est = pc._chol_cond_estimate(chol)
+        assert cond / 4 <= est <= cond * 1.001, (cond, est)              # a lower bound, within the safety factor
+        diag = chol.diagonal()
+        if not expect_chol:
+            assert float((diag.max() / diag.min()) ** 2) < cond / 100       # the diagonal test would have been fooled
+        assert (4.0 * est < pc.CHOL_COND_LIMIT) == expect_chol
+        got, ref = pc._inv_sqrt_apply(acc_t, c_mat), reference(c_mat)
+        s_got, s_ref = torch.linalg.svdvals(got), torch.linalg.svdvals(ref)
+        assert float(((s_got - s_ref).abs() / s_ref).max()) < (1e-9 if expect_chol else 1e-6)
+        u_got, u_ref = torch.linalg.svd(got, full_matrices=False)[0], torch.linalg.svd(ref, full_matrices=False)[0]
+        lead = 8                                                           # well-separated leading directions
+        assert float((u_got[:, :lead].T @ u_ref[:, :lead]).abs().diagonal().min()) > 1 - 1e-6
+
+
+def test_row_windows_keep_16_byte_alignment_for_any_even_feature_count():
+    from xgpr_amd import preconditioner as pc
+    for m in (1026, 2050, 4098, 8192, 30):
+        step = max(8192, pc.ROW_WINDOW_BYTES // (4 * m)) // 4 * 4
+        assert step % 4 == 0 and (step * m * 4) % 16 == 0

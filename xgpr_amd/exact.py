@@ -68,9 +68,27 @@ def calc_variance_exact(kernel, dataset, variance_rffs):
 
 
 def predict_mean(kernel, weights, input_x, trainy_mean, trainy_std, sequence_lengths=None, chunk_size=2000):
-    """xgp_regression.py:77-145, mean only: per chunk ``(Z * w).sum(1)``, then un-standardise."""
+    """xgp_regression.py:77-145, mean only: ``(Z * w).sum(1)`` chunk by chunk, then un-standardise.  For the
+    fixed-vector kernels float64 Z is never written: a chunk's float32 feature rows (exactly the values the float64
+    operator output is the widening of) go through the one-column projection on the float64 matrix cores
+    (``xgpr_zcache_block_project_f32``, k = 1), which applies scale and intercept; other kernels multiply
+    ``transform_x`` output."""
+    from . import xgpr_hip_rfgen_ext as ext
     preds = []
+    fused = (getattr(kernel, "supports_fused", False) and kernel.block_ok() and hasattr(kernel, "fill_feature_cache")
+             and torch.device(kernel.device).type == "cuda")
+    if fused:
+        from .kernels import scale_input
+        wcol = weights.to(torch.float64).reshape(-1, 1).contiguous()
     for i in range(0, input_x.shape[0], chunk_size):
+        if fused:
+            xs = scale_input(kernel._as_device_f32(input_x[i:i + chunk_size]), kernel.hyperparams[1])
+            zc = torch.empty((xs.shape[0], kernel.get_num_rffs()), dtype=torch.float32, device=kernel.device)
+            kernel.fill_feature_cache(xs, zc)
+            pred = torch.empty((xs.shape[0], 1), dtype=torch.float64, device=kernel.device)
+            ext.hipZCacheBlockProject(zc, wcol, pred, kernel.fit_intercept, 0.0)
+            preds.append(pred[:, 0])
+            continue
         sl = None if sequence_lengths is None else sequence_lengths[i:i + chunk_size]
         z = kernel.transform_x(input_x[i:i + chunk_size], sl)
         preds.append((z * weights[None, :]).sum(dim=1))

@@ -315,11 +315,18 @@ class ConvSORFKernel(KernelBase):
         # (3.5 ms per 1024 sequences = 2.9e5 sequences/s against 3.5e5 on 8192-sequence launches)
         n = dataset.get_local_ndatapoints()
         zc = torch.empty((n, self.num_rffs), dtype=torch.float32, device=self.device)
+        if not hasattr(dataset, "get_xdata"):        # any other dataset class: its own chunks
+            lo = 0
+            for xdata, ldata in dataset.get_chunked_x_data():
+                zc[lo:lo + xdata.shape[0]] = self.transform_x(xdata, ldata).to(torch.float32)
+                lo += xdata.shape[0]
+            return zc
         xall, lall = dataset.get_xdata(), dataset.get_sequence_lengths()
         step = max(1, min(self.CACHE_BUILD_ROWS, (1 << 30) // (8 * self.num_rffs)))      # float64 temporary <= 1 GiB
         for lo in range(0, n, step):
             hi = min(lo + step, n)
-            zc[lo:hi] = self.transform_x(xall[lo:hi], lall[lo:hi]).to(torch.float32)
+            # (no sequence lengths: transform_x raises the reference's "sequence_length is required" error)
+            zc[lo:hi] = self.transform_x(xall[lo:hi], None if lall is None else lall[lo:hi]).to(torch.float32)
         return zc
 
     CACHE_BUILD_ROWS = 8192

@@ -46,7 +46,7 @@ def _row_windows(dataset, kernel, from_cache, with_y):
     m = kernel.get_num_rffs()
     n = dataset.get_local_ndatapoints()
     yall = dataset.normalized_y() if with_y else None
-    step = max(8192, ROW_WINDOW_BYTES // (4 * m))
+    step = max(8192, ROW_WINDOW_BYTES // (4 * m)) // 4 * 4       # whole groups of 4 rows: window bases stay 16-byte aligned for any even m
     if from_cache:
         zc = dataset.feature_cache(kernel)
         for lo in range(0, n, step):
@@ -188,7 +188,30 @@ def _first_pass(dataset, rank, kernel, random_state, verbose, is_regression=True
 GRAM_COND_LIMIT = 1e7        # eigenvalue ratio up to which the Gram-matrix route keeps ~1e-9 relative accuracy
 
 
-CHOL_DIAG_LIMIT = 1e6        # (max / min diagonal of the Cholesky factor)^2 up to which the triangular route is taken
+CHOL_COND_LIMIT = 1e6        # estimated condition number of the sketch up to which the triangular route is taken
+CHOL_COND_ITERS = 12
+
+
+def _chol_cond_estimate(chol):
+    """Estimate of cond_2(C) for C = L L^T from its Cholesky factor: largest eigenvalue of C by power iteration on
+    L L^T, smallest by inverse power iteration (two triangular solves per step) -- a few dozen rank x rank launches, no
+    host synchronisation before the final read.  Both iterations approach their eigenvalue from inside the spectrum,
+    so the product is a lower bound that a dozen steps from a generic start bring within a small factor; the caller
+    applies a safety factor.  (The ratio of the extreme diagonal entries of L, which this replaces, also only bounds
+    cond(C) from below -- but by orders of magnitude for rotated spectra.)"""
+    n = chol.shape[0]
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    v = torch.randn(n, 1, generator=gen, dtype=torch.float64).to(chol.device)
+    w = v.clone()
+    top = bot = None
+    for _ in range(CHOL_COND_ITERS):
+        v = chol @ (chol.T @ v)
+        top = torch.linalg.vector_norm(v)
+        v = v / top
+        w = torch.linalg.solve_triangular(chol.T, torch.linalg.solve_triangular(chol, w, upper=False), upper=True)
+        bot = torch.linalg.vector_norm(w)
+        w = w / bot
+    return float((top * bot).item())
 
 
 def _inv_sqrt_apply(acc_t, c_mat):
@@ -202,8 +225,8 @@ def _inv_sqrt_apply(acc_t, c_mat):
     if float((c_mat - c_mat.T).abs().max().item()) <= 1e-9 * float(c_mat.abs().max().item()):
         chol, info = torch.linalg.cholesky_ex(c_sym)
         if int(info.item()) == 0:
-            diag = chol.diagonal()
-            if float((diag.max() / diag.min()).item()) ** 2 < CHOL_DIAG_LIMIT:
+            cond = _chol_cond_estimate(chol)
+            if np.isfinite(cond) and 4.0 * cond < CHOL_COND_LIMIT:           # (4: the estimate is a lower bound)
                 return torch.linalg.solve_triangular(chol, acc_t.T, upper=False).T
         evals, evecs = torch.linalg.eigh(c_sym)
         if float(evals[0].item()) * GRAM_COND_LIMIT > float(evals[-1].item()) > 0:
