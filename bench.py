@@ -518,7 +518,7 @@ def main():
         # measured on, and labelled as such in the line
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
             c = pm["config"]
             if (c["rows_per_gpu"], c["dim"], c["rffs"]) == (n_local, d, m):
                 traffic = pm["hbm_bytes_per_launch"]
@@ -573,7 +573,7 @@ def main():
                        "rows_per_gpu": n_local, "lambda": 0.1, "sigma": 1.0},
             "roofline": {"kernel": "ztz3_kernel<10> (+ pack_radem, reduce_slabs)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc passes of this "
+                         "traffic": traffic, "traffic_source": "profiles/r3_pmc_traffic.json (rocprofv3 --pmc passes of this "
                          "command; stored, not re-measured in this run)" if traffic is not None else None,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
                          "vector_pipe": vector_pipe,

@@ -265,6 +265,18 @@ int xgpr_sketch_gemm_f64(const double *A, long lda, const float *zc, long n, lon
                          long I, int bt, int trans_out, double scale, int fit_intercept, int accumulate,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the dense Z^T Z accumulation of exact mode, the variance matrix and crude tuning
+ * (scoring_toolkit/exact_nmll_calcs.py:42-78 calc_design_mat `z_trans_z += xfeatures.T @ xfeatures`, :116-139
+ * calc_var_design_mat, scoring_toolkit/lb_optimizer.py:68-117 get_eigvals) on the float64 matrix cores with BOTH
+ * operands the float32 feature rows (Z = scale * zc, Z[:, 0] = 1 when fit_intercept; scale as above):
+ *     C[msub, msub] (+)= Z[:, :msub]^T Z[:, :msub]
+ * float64 Z is never written.  Only tiles on or above the diagonal are computed; both triangles are stored.  msub a
+ * multiple of 128 <= num_rffs (the reference's variance step uses the leading variance_rffs features), num_rffs a
+ * multiple of 4, ldc even >= msub.  Deterministic.  Workspace: xgpr_ztz_gram_workspace_bytes(msub, n). */
+size_t xgpr_ztz_gram_workspace_bytes(long msub, long n);
+int xgpr_ztz_gram_f64(const float *zc, long n, long num_rffs, double *C, long ldc, long msub, double scale,
+                      int fit_intercept, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- cudaMiniARDGrad(inputArr, outputArr, precompWeights, sigmaMap, sigmaVals, gradArr, fitIntercept)
  * (gpu_rf_gen/xgpr_cuda_rfgen_cpp_ext.cpp:50-60; cpu_rf_gen/rbf_ops/ard_ops.cpp:39-124): MiniARD random
  * features out[n, num_rffs] and their gradient grad[n, num_rffs, num_lengthscales] w.r.t. the per-group

@@ -33,4 +33,4 @@ for kname, (d, issued, useful) in SPEC.items():
     print(kname, json.dumps(out[kname]))
 out["note"] = ("durations are under the profiler (a few % longer than the un-profiled launches); SQ_VALU_MFMA_BUSY_CYCLES "
                "saturates at 2^35 on launches this long and is recorded only for completeness")
-json.dump(out, open(os.path.join(ROOT, "profiles", "r2_mfma_clock.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", os.environ.get("XGPR_ROUND", "r3") + "_mfma_clock.json"), "w"), indent=1)

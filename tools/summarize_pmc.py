@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-ROUND = "r2"
+ROUND = os.environ.get("XGPR_ROUND", "r3")
 
 
 def one(pattern):
@@ -51,13 +51,13 @@ def mean_main(vals):
 
 note = ("gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported; "
         "separate --pmc passes with --kernel-trace only (tools/collect_profiles.sh)")
-for short, kname, alg in (("fused", "ztz3_kernel<10>", 4.0 * d * n_local),
+for short, kname, alg in (("fused", "ztz3_kernel<10, Z3_MATVEC>", 4.0 * d * n_local),
                           ("cached", "zcache_ztz_kernel<true, 2>", 4.0 * m * n_local)):
     if short not in per:
         continue
     fk, wk = mean_main(per[short]["FETCH_SIZE"]), mean_main(per[short]["WRITE_SIZE"])
     hbm = (2.0 * fk + wk) * 1024.0
-    out = {"round": 2, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
+    out = {"round": int(ROUND[1:]), "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
            "--steps 3 --warmup 1 --no-cpu-baseline", "kernel": kname,
            "config": {"rows_per_gpu": n_local, "dim": d, "rffs": m, "n_gpus": 1},
            "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk, "correction": note,

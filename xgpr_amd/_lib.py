@@ -48,6 +48,7 @@ SIGNATURES = {
     "xgpr_zcache_block_backproject_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _i, _vp, _sz, _vp],
     "xgpr_srht_sample_rows_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _d, _i, _vp, _sz, _vp],
     "xgpr_sketch_gemm_f64": [_vp, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _d, _i, _i, _vp, _sz, _vp],
+    "xgpr_ztz_gram_f64": [_vp, _l, _l, _vp, _l, _l, _d, _i, _i, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
 }
 SIZE_FUNCS = {
@@ -59,6 +60,7 @@ SIZE_FUNCS = {
     "xgpr_zcache_block_workspace_bytes": [_l, _l, _l],
     "xgpr_srht_sample_workspace_bytes": [_l],
     "xgpr_sketch_gemm_workspace_bytes": [_l, _l, _l, _l, _i],
+    "xgpr_ztz_gram_workspace_bytes": [_l, _l],
 }
 STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch"]
 

@@ -41,6 +41,7 @@ namespace {
 #include "zcache.inc"
 #include "zblock.inc"
 #include "sketch_gemm.inc"
+#include "gram.inc"
 #include "mini_ard.inc"
 #include "cg_kernels.inc"
 #include "launchers.inc"
@@ -198,6 +199,12 @@ int xgpr_sketch_gemm_f64(const double *A, long lda, const float *zc, long n, lon
                          void *workspace, size_t workspace_bytes, void *stream) {
     return sketch_gemm_impl(A, lda, zc, n, num_rffs, C, ldc, I, bt, trans_out, scale, fit_intercept, accumulate, workspace,
                             workspace_bytes, stream);
+}
+
+size_t xgpr_ztz_gram_workspace_bytes(long msub, long n) { return gram_workspace_bytes(msub, n); }
+int xgpr_ztz_gram_f64(const float *zc, long n, long num_rffs, double *C, long ldc, long msub, double scale,
+                      int fit_intercept, int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+    return gram_impl(zc, n, num_rffs, C, ldc, msub, scale, fit_intercept, accumulate, workspace, workspace_bytes, stream);
 }
 
 int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, double *r_next, const double *z,

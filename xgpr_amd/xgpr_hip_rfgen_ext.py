@@ -243,6 +243,31 @@ def hipSketchGemm(aMat, cacheArr, outArr, nrows, bt, transOut, fitIntercept, sca
                                                 C.c_size_t(workspace.numel()), _stream()))
 
 
+def gram_ok(num_rffs, msub):
+    """Shapes hipZtZGram covers: whole 128 x 128 tiles of the leading msub features."""
+    return msub % 128 == 0 and 0 < msub <= num_rffs and num_rffs % 4 == 0
+
+
+def hipZtZGram(cacheArr, outArr, fitIntercept, scale=0.0, accumulate=False, workspace=None):
+    """``outArr[msub, msub] (+)= Z[:, :msub].T @ Z[:, :msub]`` with msub = outArr.shape[0] on the float64 matrix cores,
+    Z = scale * cacheArr float32 rows with Z[:, 0] = 1 when fitIntercept (exact_nmll_calcs.py:42-78, :116-139;
+    lb_optimizer.py:68-117) -- both operands from the float32 rows, no float64 copy of Z.  Returns the workspace used
+    (pass it back in to avoid reallocation)."""
+    zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
+    op = _dev(outArr, "outArr", torch.float64, 2)
+    n, m = cacheArr.shape
+    msub = outArr.shape[0]
+    if outArr.shape[1] < msub or not gram_ok(m, msub):
+        raise RuntimeError("incorrect array dims passed")
+    need = int(_LIB.xgpr_ztz_gram_workspace_bytes(msub, n))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=cacheArr.device)
+    _lib.check(_LIB.xgpr_ztz_gram_f64(zc, n, m, op, outArr.shape[1], msub, float(scale), int(bool(fitIntercept)),
+                                      int(bool(accumulate)), C.c_void_p(workspace.data_ptr()),
+                                      C.c_size_t(workspace.numel()), _stream()))
+    return workspace
+
+
 def sketch_gemm_workspace_bytes(nrows, jdim, kdim, ldc, trans_out):
     return int(_LIB.xgpr_sketch_gemm_workspace_bytes(nrows, jdim, kdim, ldc, int(bool(trans_out))))
 
