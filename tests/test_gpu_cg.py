@@ -15,6 +15,7 @@ DEV = "cuda"
 
 def rel(a, b):
     a = a.cpu().numpy() if isinstance(a, torch.Tensor) else a
+    b = b.cpu().numpy() if isinstance(b, torch.Tensor) else b
     return np.linalg.norm(a - b) / np.linalg.norm(b)
 
 
@@ -185,10 +186,22 @@ def test_g9_exact_fit_and_variance():
     ds = build_regression_dataset(x, y, chunk_size=2000, device=DEV)
     kern = make_kernel("RBF", x.shape, 512, 123, DEV, {"intercept": True})
     kern.set_hyperparams(g9["hparam_log"], logspace=True)
+    from xgpr_amd.exact import gram_route, calc_design_mat
+    assert gram_route(ds, kern, 512) is False          # Z^T Z on the matrix cores from regenerated float32 windows
     w, _, _ = calc_weights_exact(ds, kern)
     assert rel(w, g9["weights"]) < 1e-5
+    # ... and the accumulated design matrix itself against the reference's formulation on float64 features
+    ztz, zty, yty = calc_design_mat(ds, kern)
+    z = kern.transform_x(x)
+    yn = ds.normalized_y()
+    assert rel(ztz, z.T @ z) < 1e-12 and rel(zty, z.T @ yn) < 1e-12 and abs(yty - float(yn @ yn)) < 1e-9 * yty
+    assert gram_route(ds, kern, 12) is None            # 12 variance features: not whole tiles, the float64 formulation
     var = calc_variance_exact(kern, ds, 12)
     assert rel(var, g9["var"]) < 1e-5
+    v128 = calc_variance_exact(kern, ds, 128)          # a whole tile: the leading block through the gram kernel
+    blk = z[:, :128].T @ z[:, :128]
+    blk.diagonal().add_(float(kern.get_lambda()) ** 2)
+    assert rel(v128, torch.linalg.pinv(blk, hermitian=True)) < 1e-8
     preds = predict_mean(kern, w, torch.from_numpy(g9["xtest"]).to(DEV), ds.get_ymean(), ds.get_ystd())
     assert np.allclose(preds.cpu().numpy(), g9["preds"], rtol=1e-5, atol=1e-6)
 

@@ -101,3 +101,34 @@ def test_srht_sample_rows_equals_separate_operators(n, m, rank, icpt):
     assert float(out[:, rank:].abs().max()) == 0.0 if ldo > rank else True
     ref_zty = z64.T @ y
     assert float((zty - ref_zty).abs().max()) <= 1e-12 * float(ref_zty.abs().max()) + 1e-14
+
+
+@pytest.mark.parametrize("n,m,msub,icpt,scale", [
+    (4096, 1024, 1024, True, 0.031),        # whole chunks; 36 tiles x 256 chunks over 512 workgroups: every tile is split
+    (1000, 512, 256, False, 1.0),           # leading block of the features (the variance step), a tail of n % 16 rows
+    (37, 256, 128, True, 0.5),              # two chunks and a tail
+    (9, 128, 128, True, 0.25),              # fewer rows than one chunk: the tail kernel alone
+    (20000, 1024, 1024, False, 0.02),       # many workgroups start inside a tile (stream-K spills)
+    (16384, 2048, 2048, True, 0.0156)])
+def test_gram_from_float32_rows(n, m, msub, icpt, scale):
+    """C[msub, msub] (+)= Z[:, :msub]^T Z[:, :msub] with both operands the float32 feature rows (xgpr_ztz_gram_f64:
+    exact_nmll_calcs.py:42-78, :116-139) against the float64 product over the same rows; both triangles, accumulation,
+    a padded row pitch, determinism."""
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    g = torch.Generator(device=DEV).manual_seed(n + m)
+    zc = torch.rand(n, m, generator=g, device=DEV) * 2 - 1
+    z = _z64(zc, scale, icpt)[:, :msub]
+    ref = z.T @ z
+    tol = 1e-13 * float(ref.abs().max()) * np.sqrt(n)
+    out = torch.full((msub, msub + 6), 7.0, dtype=torch.float64, device=DEV)      # ldc > msub: the padding stays untouched
+    ws = ext.hipZtZGram(zc, out, icpt, scale)
+    assert float((out[:, :msub] - ref).abs().max()) <= tol
+    assert torch.equal(out[:, :msub], out[:, :msub].T.contiguous())                # mirrored exactly
+    assert bool((out[:, msub:] == 7.0).all())
+    ext.hipZtZGram(zc, out, icpt, scale, accumulate=True, workspace=ws)
+    assert float((out[:, :msub] - 2 * ref).abs().max()) <= 2 * tol
+    again = torch.zeros((msub, msub), dtype=torch.float64, device=DEV)
+    first = torch.zeros_like(again)
+    ext.hipZtZGram(zc, first, icpt, scale, workspace=ws)
+    ext.hipZtZGram(zc, again, icpt, scale, workspace=ws)
+    assert torch.equal(first, again)                                               # deterministic

@@ -31,18 +31,25 @@ def get_eigvals(kernel, dataset, subsample=1):
     z_trans_z, z_trans_y = torch.zeros((m, m), **f64), torch.zeros(m, **f64)
     stats = torch.zeros(2, **f64)                    # y^T y, number of datapoints used
     rng = np.random.default_rng(123)
-    for xin, yin, ldata in dataset.get_chunked_data():
-        if subsample != 1:
-            idx_size = max(1, int(subsample * xin.shape[0]))
-            idx = rng.choice(xin.shape[0], idx_size, replace=False)
-            tidx = torch.from_numpy(idx).to(xin.device)
-            xin, yin = xin[tidx, ...], yin[tidx]
-            ldata = None if ldata is None else ldata[idx]
-        xtrans, ydata = kernel.transform_x_y(xin, yin, ldata)
-        z_trans_z += xtrans.T @ xtrans
-        z_trans_y += xtrans.T @ ydata
-        stats[0] += ydata @ ydata
-        stats[1] += xtrans.shape[0]
+    from .exact import gram_route, accumulate_gram_rows
+    route = gram_route(dataset, kernel, m) if subsample == 1 else None
+    if route is not None:
+        # all rows: Z^T Z and Z^T y from float32 feature rows on the matrix cores (xgpr_ztz_gram_f64), no float64 Z
+        stats[0] += accumulate_gram_rows(dataset, kernel, z_trans_z, route, z_trans_y)[0]
+        stats[1] += dataset.get_local_ndatapoints()
+    else:
+        for xin, yin, ldata in dataset.get_chunked_data():
+            if subsample != 1:
+                idx_size = max(1, int(subsample * xin.shape[0]))
+                idx = rng.choice(xin.shape[0], idx_size, replace=False)
+                tidx = torch.from_numpy(idx).to(xin.device)
+                xin, yin = xin[tidx, ...], yin[tidx]
+                ldata = None if ldata is None else ldata[idx]
+            xtrans, ydata = kernel.transform_x_y(xin, yin, ldata)
+            z_trans_z += xtrans.T @ xtrans
+            z_trans_y += xtrans.T @ ydata
+            stats[0] += ydata @ ydata
+            stats[1] += xtrans.shape[0]
     for t in (z_trans_z, z_trans_y, stats):
         comm.all_reduce_(t)
     z_trans_z.diagonal().add_(1e-5)
