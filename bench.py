@@ -87,7 +87,19 @@ def dist_summary(comm, device, m):
     ones = torch.ones(1, dtype=torch.float64, device=device)
     comm.all_reduce_(ones)
     out = {"n_ranks_seen": int(round(float(ones.item()))), "world_size": comm.world_size,
-           "backend": dist.get_backend() if comm.through_backend else "none (single rank)"}
+           "backend": dist.get_backend() if comm.through_backend else "none (single rank)",
+           "allreduce_path": ("xgpr_allreduce_sum_f64: ncclAllReduce enqueued on the compute stream (communicator created through "
+                              "the C ABI)" if getattr(comm, "direct_rccl", False) else
+                              "torch.distributed.all_reduce (ProcessGroup's stream, chained to the compute stream with events)")
+                             if comm.through_backend else "none"}
+    if comm.through_backend and getattr(comm, "direct_rccl", False):
+        # cross-check of the direct path against torch.distributed's own all-reduce on a non-trivial vector
+        import torch.distributed as dist2
+        chk = torch.arange(1, 1025, dtype=torch.float64, device=device) * (comm.rank + 1)
+        ref = chk.clone()
+        comm.all_reduce_(chk)
+        dist2.all_reduce(ref, op=dist2.ReduceOp.SUM)
+        out["direct_equals_torch_allreduce"] = bool(torch.equal(chk, ref))
     if comm.through_backend:
         w = torch.zeros(m, dtype=torch.float64, device=device)
         for _ in range(5):
@@ -588,9 +600,8 @@ def main():
             "distributed": {**dist_info,
                             "per_rank": [{"rank": i, "ms_per_step": v[0], "fused_kernel_ms": v[1],
                                           "allreduce_ms_per_iter": v[2], "rows": int(v[3])} for i, v in enumerate(per_rank)],
-                            "allreduce_note": "torch.distributed all_reduce (RCCL on ProcessGroupNCCL's stream, chained to "
-                                              "the compute stream with events); allreduce_ms_per_iter is measured by HIP "
-                                              "events on the compute stream around the call, inside the timed CG iterations"},
+                            "allreduce_note": "allreduce_ms_per_iter is measured by HIP events on the compute stream around the "
+                                              "all-reduce of w (allreduce_path), inside the timed CG iterations"},
             "final_loss": losses[-1],
             "precond_build": {"seconds": precond_build_s, "first_build_seconds": precond_first_s, "rows": n,
                               "rank": args.rank_precond, "method": "srht",

@@ -327,6 +327,20 @@ int xgpr_zcache_block_backproject_f32(const float *zc, const double *r, double *
  * bit h of lane clear -> 2 lane + h + 128 r, set -> -h. */
 int xgpr_selftest_lane_xor(int32_t *out, void *stream);
 
+/* ---- the exchange step of the sharded path issued on the caller's stream.  The reference is single-device
+ * (docs/FAQ.rst:12-15); its loops `for chunk: w += Z.T @ (Z @ v)` (fitting_toolkit/cg_tools.py:189-191) and
+ * `acc += ...` (preconditioners/rand_nys_constructors.py:115-119) become per-rank partial sums, and these entry points
+ * add them up with RCCL's all-reduce ENQUEUED ON `stream` -- directly behind the kernel that produced the partial sum,
+ * with no hand-off to another stream.  xgpr_rccl_load(path) resolves the RCCL library the process already uses
+ * (dlopen; NULL / "" = "librccl.so"); xgpr_rccl_unique_id fills 128 bytes (ncclUniqueId) on one rank, which the host
+ * side distributes by any means (here: the torch.distributed store); every rank then calls xgpr_rccl_comm_init.
+ * buf: float64 [n] on the device, summed in place over all ranks. */
+int xgpr_rccl_load(const char *path);
+int xgpr_rccl_unique_id(char *out128);
+int xgpr_rccl_comm_init(void **comm, int nranks, const char *id128, int rank);
+int xgpr_allreduce_sum_f64(void *comm, double *buf, long n, void *stream);
+int xgpr_rccl_comm_destroy(void *comm);
+
 #ifdef __cplusplus
 }
 #endif

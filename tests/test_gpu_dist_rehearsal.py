@@ -24,3 +24,18 @@ def test_one_rank_through_rccl():
     out = json.loads(lines[0])
     assert out["backend"] == "nccl" and out["world_size"] == 1 and out["n_ranks_seen"] == 1
     assert out["allreduce_w_us_back_to_back"] > 0 and out["shard_rows_per_rank"] == [1000.0]
+    # the float64 sums go through the C ABI's on-stream all-reduce (a communicator of its own), and agree with torch's
+    assert out["allreduce_path"].startswith("xgpr_allreduce_sum_f64") and out["direct_equals_torch_allreduce"] is True
+
+
+def test_one_rank_torch_distributed_fallback():
+    """XGPR_RCCL_DIRECT=0 keeps every collective on torch.distributed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"XGPR_DIST_FORCE": "1", "XGPR_RCCL_DIRECT": "0",
+                "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29548", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-check", "--rows", "1000"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["allreduce_path"].startswith("torch.distributed") and out["n_ranks_seen"] == 1

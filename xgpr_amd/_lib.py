@@ -50,6 +50,11 @@ SIGNATURES = {
     "xgpr_sketch_gemm_f64": [_vp, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _d, _i, _i, _vp, _sz, _vp],
     "xgpr_ztz_gram_f64": [_vp, _l, _l, _vp, _l, _l, _d, _i, _i, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
+    "xgpr_rccl_load": [C.c_char_p],
+    "xgpr_rccl_unique_id": [_vp],
+    "xgpr_rccl_comm_init": [_vp, _i, _vp, _i],
+    "xgpr_allreduce_sum_f64": [_vp, _vp, _l, _vp],
+    "xgpr_rccl_comm_destroy": [_vp],
 }
 SIZE_FUNCS = {
     "xgpr_rbf_workspace_bytes": [_l],

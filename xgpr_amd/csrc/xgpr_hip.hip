@@ -27,7 +27,10 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <string>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is resolved at run time (xgpr_rccl_load), never linked
 
 #include "../../include/xgpr_hip.h"
 
@@ -299,6 +302,73 @@ int xgpr_srht_sample_f32(const float *z, const int8_t *radem, const long *sample
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
     HIP_TRY(hipGetLastError(), "selftest_kernel launch");
+    return 0;
+}
+
+// ---- RCCL on the caller's stream.  torch.distributed's all-reduce runs RCCL on ProcessGroupNCCL's own stream and
+// chains it to the compute stream with an event on each side; the 64 KiB exchange of a CG iteration is latency-bound, so
+// these entry points enqueue ncclAllReduce directly on the stream the matvec's slab reduction was launched on.  RCCL is
+// the copy the process already uses (the path handed to xgpr_rccl_load: torch ships its own librccl.so), resolved with
+// dlopen / dlsym so that libxgpr_hip.so carries no link-time dependency on it.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*get_unique_id)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*comm_init_rank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*all_reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    const char *(*get_error_string)(ncclResult_t) = nullptr;
+} g_rccl;
+int rccl_fail(ncclResult_t r, const char *what) {
+    g_err = std::string(what) + ": " + (g_rccl.get_error_string ? g_rccl.get_error_string(r) : "RCCL error");
+    return XGPR_ERR_HIP;
+}
+}  // namespace
+
+int xgpr_rccl_load(const char *path) {
+    if (g_rccl.lib) return 0;
+    void *lib = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(XGPR_ERR_UNSUPPORTED, "xgpr_rccl_load: could not open the RCCL library");
+    g_rccl.get_unique_id = reinterpret_cast<decltype(g_rccl.get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.comm_init_rank = reinterpret_cast<decltype(g_rccl.comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.all_reduce = reinterpret_cast<decltype(g_rccl.all_reduce)>(dlsym(lib, "ncclAllReduce"));
+    g_rccl.comm_destroy = reinterpret_cast<decltype(g_rccl.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.get_error_string = reinterpret_cast<decltype(g_rccl.get_error_string)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy)
+        return fail(XGPR_ERR_UNSUPPORTED, "xgpr_rccl_load: the library does not export the RCCL entry points");
+    g_rccl.lib = lib;
+    return 0;
+}
+int xgpr_rccl_unique_id(char *out128) {
+    if (!g_rccl.lib) return fail(XGPR_ERR_UNSUPPORTED, "RCCL not loaded (xgpr_rccl_load)");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.get_unique_id(&id);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclGetUniqueId");
+    memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+int xgpr_rccl_comm_init(void **comm, int nranks, const char *id128, int rank) {
+    if (!g_rccl.lib) return fail(XGPR_ERR_UNSUPPORTED, "RCCL not loaded (xgpr_rccl_load)");
+    if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect communicator arguments");
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t c = nullptr;
+    ncclResult_t r = g_rccl.comm_init_rank(&c, nranks, id, rank);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitRank");
+    *comm = c;
+    return 0;
+}
+int xgpr_allreduce_sum_f64(void *comm, double *buf, long n, void *stream) {
+    if (!g_rccl.lib || !comm) return fail(XGPR_ERR_UNSUPPORTED, "no RCCL communicator (xgpr_rccl_comm_init)");
+    if (n <= 0) return 0;
+    ncclResult_t r = g_rccl.all_reduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce");
+    return 0;
+}
+int xgpr_rccl_comm_destroy(void *comm) {
+    if (!g_rccl.lib || !comm) return 0;
+    ncclResult_t r = g_rccl.comm_destroy((ncclComm_t)comm);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclCommDestroy");
     return 0;
 }
 

@@ -7,7 +7,16 @@ preconditioners/rand_nys_constructors.py:115-119), so rows are sharded contiguou
 replicated CG state stays identical on every rank without further communication.
 
 On a CPU-only box the same code runs over the ``gloo`` backend (tests/test_dist_cpu.py).
+
+Where the sum runs.  ``torch.distributed.all_reduce`` issues the RCCL kernel on ProcessGroupNCCL's own stream and
+chains it to the compute stream with an event on each side.  For the float64 sums of this path (64 KiB per CG
+iteration: latency-bound) ``Comm`` instead owns a second RCCL communicator, created through the C ABI
+(``xgpr_rccl_comm_init``; the 128-byte id travels through torch.distributed's own channel) and calls
+``xgpr_allreduce_sum_f64``: ``ncclAllReduce`` enqueued on the CURRENT stream, directly behind the kernel that wrote
+the partial sum.  ``XGPR_RCCL_DIRECT=0`` keeps everything on torch.distributed; the direct path is also dropped (on all
+ranks together) if its set-up or its self test -- a sum of ones -- fails.
 """
+import ctypes
 import os
 
 import torch
@@ -22,6 +31,50 @@ class Comm:
         # one-rank rehearsal of the collective path (XGPR_DIST_FORCE=1): the calls go to the backend even though
         # there is nobody to exchange with, so that communicator set-up and stream ordering are exercised on one GPU
         self.through_backend = through_backend or world_size > 1
+        self._rccl = None                 # ncclComm_t of the direct path (enable_direct_rccl)
+
+    def enable_direct_rccl(self, device):
+        """Create this rank's communicator for the on-stream all-reduce (module docstring).  Collective: every rank
+        calls it.  Returns True when the direct path is in use."""
+        if not self.through_backend or os.environ.get("XGPR_RCCL_DIRECT", "1") == "0" or dist.get_backend(self.group) != "nccl":
+            return False
+        ok = 1
+        try:
+            from xgpr_amd import _lib          # (absolute: bench.py --dist-check loads this file by path)
+            lib = _lib.load()
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            _lib.check(lib.xgpr_rccl_load((path if os.path.exists(path) else "librccl.so").encode()))
+            ident = ctypes.create_string_buffer(128)
+            if self.rank == 0:
+                _lib.check(lib.xgpr_rccl_unique_id(ctypes.cast(ident, ctypes.c_void_p)))
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            ident = ctypes.create_string_buffer(box[0], 128)
+            handle = ctypes.c_void_p()
+            _lib.check(lib.xgpr_rccl_comm_init(ctypes.cast(ctypes.byref(handle), ctypes.c_void_p), self.world_size,
+                                               ctypes.cast(ident, ctypes.c_void_p), self.rank))
+            self._rccl = handle
+            probe = torch.ones(8, dtype=torch.float64, device=device)
+            self._direct_sum(probe)
+            torch.cuda.synchronize(device)
+            if not bool((probe == float(self.world_size)).all()):
+                ok = 0
+        except (RuntimeError, OSError, AttributeError, ImportError):
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)       # all ranks keep or drop the direct path together
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            self._rccl = None
+        return self._rccl is not None
+
+    def _direct_sum(self, tensor):
+        from xgpr_amd import _lib
+        _lib.check(_lib.load().xgpr_allreduce_sum_f64(self._rccl, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),
+                                                      ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)))
+
+    @property
+    def direct_rccl(self):
+        return self._rccl is not None
 
     @property
     def is_distributed(self):
@@ -30,7 +83,10 @@ class Comm:
     def all_reduce_(self, tensor):
         """In-place sum over ranks (RCCL ring / tree over xGMI on GPUs)."""
         if self.through_backend:
-            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+            if self._rccl is not None and tensor.dtype == torch.float64 and tensor.is_cuda and tensor.is_contiguous():
+                self._direct_sum(tensor)
+            else:
+                dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
     def all_reduce_max_(self, tensor):
@@ -54,6 +110,27 @@ class Comm:
 SINGLE = Comm()
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on the C-level stdout when the first communicator of a process is created; the
+    benchmark's contract is ONE JSON line on stdout.  While communicators are set up, file descriptor 1 points at
+    stderr, and libc's buffer is flushed before it is put back."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def init_from_env(device_type="cuda"):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as set by
     ``python -m torch.distributed.run``) and bind this process to its GPU."""
@@ -72,10 +149,19 @@ def init_from_env(device_type="cuda"):
         return Comm()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    if not dist.is_initialized():
-        backend = os.environ.get("XGPR_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
-        kwargs = {}
-        if device_type == "cuda" and backend == "nccl":
-            kwargs["device_id"] = torch.device("cuda", local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
-    return Comm(rank, world, through_backend=force)
+    with _stdout_to_stderr():
+        if not dist.is_initialized():
+            backend = os.environ.get("XGPR_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+            kwargs = {}
+            if device_type == "cuda" and backend == "nccl":
+                kwargs["device_id"] = torch.device("cuda", local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        comm = Comm(rank, world, through_backend=force)
+        if device_type == "cuda":
+            # the first collective creates torch's communicator (if init_process_group has not), enable_direct_rccl
+            # this package's own
+            warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local))
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+            comm.enable_direct_rccl(torch.device("cuda", local))
+    return comm
