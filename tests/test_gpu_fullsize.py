@@ -225,3 +225,24 @@ def test_cfg3_full_size_matvec_is_the_sum_of_its_shards_and_reproducible():
         k.zty(x[lo:hi], y[lo:hi], part, ws)
         zty_parts += part
     assert float((zty - zty_parts).abs().max() / zty.abs().max()) < 1e-12
+
+
+def test_two_pass_matvec_across_row_windows_is_additive():
+    """More than 8192 frequencies: the matvec runs as a dot pass + an update pass per window of 131 072 rows, slabs
+    accumulating over windows.  A launch that spans two windows equals the sum of the two parts, and is reproducible."""
+    from xgpr_amd.kernels import make_kernel
+    n, d, m = 150_000, 128, 18_434
+    k = make_kernel("RBF", (n, d), m, 123, DEV, {})
+    k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+    x = _data(n, d, seed=5)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    v = torch.randn(m, dtype=torch.float64, device=DEV, generator=g)
+    ws = torch.empty(k.workspace_bytes(), dtype=torch.uint8, device=DEV)
+    full, again, a, b = (torch.empty_like(v) for _ in range(4))
+    k.ztz_matvec(x, v, full, ws)
+    k.ztz_matvec(x, v, again, ws)
+    assert torch.equal(full, again)
+    k.ztz_matvec(x[:131_072], v, a, ws)
+    k.ztz_matvec(x[131_072:], v, b, ws)
+    assert float((full - (a + b)).abs().max() / full.abs().max()) < 1e-12

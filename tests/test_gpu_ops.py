@@ -245,7 +245,10 @@ def test_error_behaviour(ext):
 @pytest.mark.parametrize("d,rffs,icpt,n", [(32, 512, True, 2000), (20, 64, False, 100), (256, 4096, True, 3000),
                                            (100, 3000, True, 777), (1024, 8192, True, 1500),
                                            (512, 16384, False, 300), (8, 2048, True, 50),
-                                           (512, 32768, True, 700), (64, 20000, True, 333), (300, 18434, False, 65)])
+                                           (512, 32768, True, 700), (64, 20000, True, 333), (300, 18434, False, 65),
+                                           # the two passes on the three-wave plan: tile groups of 2, 4 and 6, a ragged last tile
+                                           (256, 18434, True, 130), (128, 22530, False, 90), (512, 26626, True, 77),
+                                           (1024, 24576, True, 50)])
 def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """hipZtZMatvec == Z.T @ (Z @ v) with Z = transform_x(x) from the oracle (incl. Z[:,0] = 1);
     f64 accumulation, so 1e-9 relative in the max norm; and bit-reproducible run to run."""
