@@ -109,7 +109,11 @@ def test_srht_sample_rows_equals_separate_operators(n, m, rank, icpt):
     (37, 256, 128, True, 0.5),              # two chunks and a tail
     (9, 128, 128, True, 0.25),              # fewer rows than one chunk: the tail kernel alone
     (20000, 1024, 1024, False, 0.02),       # many workgroups start inside a tile (stream-K spills)
-    (16384, 2048, 2048, True, 0.0156)])
+    (16384, 2048, 2048, True, 0.0156),
+    # one tile, 1 .. 11 chunks of 16 rows: every tail length of the chunk loop unrolled by 6 (and its pipeline prologue)
+    (16, 128, 128, True, 0.5), (32, 128, 128, False, 0.5), (48, 128, 128, True, 0.5), (64, 128, 128, True, 0.5),
+    (80, 128, 128, False, 0.5), (96, 128, 128, True, 0.5), (112, 128, 128, True, 0.5), (133, 128, 128, False, 0.5),
+    (176, 256, 256, True, 0.5), (208, 256, 128, True, 0.5)])
 def test_gram_from_float32_rows(n, m, msub, icpt, scale):
     """C[msub, msub] (+)= Z[:, :msub]^T Z[:, :msub] with both operands the float32 feature rows (xgpr_ztz_gram_f64:
     exact_nmll_calcs.py:42-78, :116-139) against the float64 product over the same rows; both triangles, accumulation,

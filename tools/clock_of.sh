@@ -13,7 +13,7 @@ n = sys.argv[1]
 f = glob.glob(f"gpurun_out/clk_{n}/*/*counter_collection.csv")[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "ztz3_kernel" in r["Kernel_Name"]:
+    if "ztz3_" in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         acc["dur"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 k = len(acc["GRBM_GUI_ACTIVE"])

@@ -38,17 +38,36 @@ class Comm:
         calls it.  Returns True when the direct path is in use."""
         if not self.through_backend or os.environ.get("XGPR_RCCL_DIRECT", "1") == "0" or dist.get_backend(self.group) != "nccl":
             return False
-        ok = 1
+        def all_agree(ok):               # every rank keeps or drops the direct path together
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item()) == 1
+
+        # Every torch.distributed collective below is reached by every rank whatever happened locally (a rank that
+        # failed a local step still takes part, with "not ok"), so that a one-sided failure cannot leave the others waiting.
+        lib = None
         try:
             from xgpr_amd import _lib          # (absolute: bench.py --dist-check loads this file by path)
             lib = _lib.load()
             path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
             _lib.check(lib.xgpr_rccl_load((path if os.path.exists(path) else "librccl.so").encode()))
-            ident = ctypes.create_string_buffer(128)
-            if self.rank == 0:
+        except (RuntimeError, OSError, AttributeError, ImportError):
+            lib = None
+        if not all_agree(1 if lib is not None else 0):
+            return False
+        box = [None]
+        if self.rank == 0:
+            try:
+                ident = ctypes.create_string_buffer(128)
                 _lib.check(lib.xgpr_rccl_unique_id(ctypes.cast(ident, ctypes.c_void_p)))
-            box = [ident.raw]
-            dist.broadcast_object_list(box, src=0, group=self.group)
+                box = [ident.raw]
+            except RuntimeError:
+                box = [None]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        if box[0] is None:
+            return False
+        ok = 1
+        try:
             ident = ctypes.create_string_buffer(box[0], 128)
             handle = ctypes.c_void_p()
             _lib.check(lib.xgpr_rccl_comm_init(ctypes.cast(ctypes.byref(handle), ctypes.c_void_p), self.world_size,
@@ -59,11 +78,9 @@ class Comm:
             torch.cuda.synchronize(device)
             if not bool((probe == float(self.world_size)).all()):
                 ok = 0
-        except (RuntimeError, OSError, AttributeError, ImportError):
+        except (RuntimeError, OSError, AttributeError):
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)       # all ranks keep or drop the direct path together
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) == 0:
+        if not all_agree(ok):
             self._rccl = None
         return self._rccl is not None
 
