@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU (development aid, not part of the test suite): random shapes through the fused
+matvec, z^T y, the feature operator, the cache rows, the block (k right-hand sides) matvec / projection and the
+convolution operator, each against the CPU oracle or a float64 torch product on the same inputs.
+    python tools/stress_parity.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from xgpr_amd import xgpr_hip_rfgen_ext as ext
+from oracle import oracle as orc      # (the checker: development tooling, like tests/)
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+orc.build(ref=False)
+oracle = orc.Oracle()
+dev = "cuda"
+worst = {}
+
+
+def note(tag, err, bar):
+    worst[tag] = max(worst.get(tag, 0.0), err / bar)
+    assert err <= bar, (tag, err, bar)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+for case in range(cases):
+    d = int(rng.choice([3, 20, 32, 100, 128, 256, 300, 512, 700, 1024]))
+    rffs = int(rng.choice([64, 512, 2048, 3000, 4096, 6144, 8192, 12288, 16384])) // 2 * 2
+    n = int(rng.integers(1, 700))
+    icpt = bool(rng.integers(0, 2))
+    radem, chi = orc.draw_sorf_params(rffs, d, int(rng.integers(1, 1000)))
+    x = (rng.standard_normal((n, d)) / np.sqrt(d) * rng.choice([1.0, 1.0, 30.0])).astype(np.float32)
+    z = np.zeros((n, rffs))
+    oracle.cpuRBFFeatureGen(x.copy(), z, radem, chi, icpt)
+    F = rffs // 2
+    scale = np.sqrt(1.0 / (F - 0.5 if icpt else F))
+    out = torch.zeros((n, rffs), dtype=torch.float64, device=dev)
+    ext.hipRBFFeatureGen(T(x), out, T(radem), T(chi), icpt)
+    note("features", float(np.abs(out.cpu().numpy() - z).max()), 4e-7 * scale)
+    if icpt:
+        z[:, 0] = 1.0
+    v = rng.standard_normal(rffs)
+    y = rng.standard_normal(n)
+    w = torch.zeros(rffs, dtype=torch.float64, device=dev)
+    ext.hipZtZMatvec(T(x), T(radem), T(chi), T(v), w, icpt)
+    ref = z.T @ (z @ v)
+    note("fused matvec", float(np.abs(w.cpu().numpy() - ref).max()), 1e-6 * float(np.abs(ref).max()))
+    zty = torch.zeros(rffs, dtype=torch.float64, device=dev)
+    ext.hipZtY(T(x), T(radem), T(chi), T(y), zty, icpt)
+    refy = z.T @ y
+    note("zty", float(np.abs(zty.cpu().numpy() - refy).max()), 1e-6 * float(np.abs(refy).max()) + 1e-12)
+    if rffs % 4 == 0:
+        zc = torch.empty((n, rffs), dtype=torch.float32, device=dev)
+        ext.hipRBFFeatureCache(T(x), zc, T(radem), T(chi))
+        zs = zc.double() * float(np.float32(scale))
+        if icpt:
+            zs[:, 0] = 1.0
+        for k in (1, int(rng.integers(2, 17)), 26, 32):
+            V = torch.from_numpy(rng.standard_normal((rffs, k))).to(dev)
+            W = torch.zeros_like(V)
+            ws = torch.empty(ext.zcache_block_workspace_bytes(n, rffs, k), dtype=torch.uint8, device=dev)
+            ext.hipZCacheBlockMatvec(zc, V, W, icpt, ws)
+            refw = zs.T @ (zs @ V)
+            note(f"block matvec", float((W - refw).abs().max()), 1e-10 * float(refw.abs().max()) + 1e-300)
+            P = torch.zeros((n, k), dtype=torch.float64, device=dev)
+            ext.hipZCacheBlockProject(zc, V, P, icpt)
+            refp = zs @ V
+            note("block project", float((P - refp).abs().max()), 1e-11 * float(refp.abs().max()) + 1e-300)
+    # convolution operator
+    C = int(rng.choice([4, 21, 64])); cw = int(rng.integers(1, 17)); L = cw + int(rng.integers(0, 40))
+    m2 = int(rng.choice([64, 600, 1024, 2048]))
+    ns = int(rng.integers(1, 9))
+    radem2, chi2 = orc.draw_sorf_params(m2, cw * C, 77, conv=True)
+    xs = rng.standard_normal((ns, L, C)).astype(np.float32)
+    sl = rng.integers(cw, L + 1, size=ns).astype(np.int32)
+    sc = int(rng.integers(0, 3))
+    refc = np.zeros((ns, m2))
+    oracle.cpuConv1dFGen(xs, refc, radem2, chi2, sl, cw, sc)
+    oc = torch.zeros((ns, m2), dtype=torch.float64, device=dev)
+    ext.hipConv1dFGen(T(xs), oc, T(radem2), T(chi2), sl, cw, sc)
+    kmax = int(sl.max()) - cw + 1
+    cscale = np.sqrt(2.0 / m2) * {0: kmax, 1: np.sqrt(kmax), 2: 1.0}[sc]
+    note("conv features", float(np.abs(oc.cpu().numpy() - refc).max()), 4e-7 * cscale)
+    print(f"case {case}: d={d} M={rffs} n={n} icpt={icpt} | conv C={C} w={cw} L={L} M={m2} ok", flush=True)
+print("worst error / bar per check:", {k: round(v, 3) for k, v in worst.items()})
