@@ -8,8 +8,8 @@
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
 Matern-5/2 kernel, N = 1e6 datapoints, d = 1024, 8192 random features, rows sharded
 contiguously over the ranks (STRONG scaling: N is the whole job), rank-512 randomized-Nystrom
-preconditioner.  Synthetic data (X ~ N(0,1)/sqrt(d) from the device RNG, seeded per rank;
-y = sin(X a) + 0.1 eps), resident in HBM before the timed region.
+preconditioner.  Synthetic data (X ~ N(0,1)/sqrt(d) from the device RNG, seeded per GLOBAL row block -- the same
+dataset at every N; y = sin(X a) + 0.1 eps), resident in HBM before the timed region.
 
 A "step" is one preconditioned-CG iteration (reference fitting_toolkit/cg_tools.py:255-287):
 one pass of the fused feature-generation + Z^T(Z p) kernel over all N rows (every iteration
@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU-baseline budget: whole 8192-row chunks are processed until this much time is spent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` object (build + fit of cfg2 / cfg4 / cfg5 at their per-GPU shares, ~15 s)")
     ap.add_argument("--dist-check", action="store_true",
                     help="rendezvous only: start / join the ranks, count them with an all-reduce, time the per-iteration "
                          "all-reduce, print the JSON line and exit (no HIP kernels; also runs on CPU over gloo)")
@@ -135,17 +137,49 @@ def gather_per_rank(comm, device, values):
     return [b.tolist() for b in bufs]
 
 
-def make_shard(n_local, d, rank, device):
+DATA_BLOCK_ROWS = 15625       # rows per seeded block of the synthetic dataset (1e6 rows = 64 blocks; 125 000 = 8 blocks)
+
+
+def make_shard(lo, hi, d, device):
+    """Rows [lo, hi) of THE synthetic dataset -- the same dataset whatever the number of ranks.  Row block b (global rows
+    b*DATA_BLOCK_ROWS ...) has its own generator seeded with b, is always drawn (and its y computed) at the full block
+    shape, then sliced to the shard, so that the concatenation of the shards of 1, 2, 4 or 8 ranks is one and the same
+    (x, y) bit for bit: X ~ N(0,1)/sqrt(d) float32, y = sin(X a) + 0.1 eps float64."""
     import numpy as np
     import torch
-    gen = torch.Generator(device=device)
-    gen.manual_seed(123 + 1000 * rank)
-    x = torch.randn((n_local, d), generator=gen, device=device, dtype=torch.float32) / np.sqrt(d)
     ga = torch.Generator(device=device)
     ga.manual_seed(7)
     a = torch.randn(d, generator=ga, device=device, dtype=torch.float32) * 3.0
-    y = torch.sin(x @ a).double() + 0.1 * torch.randn(n_local, generator=gen, device=device, dtype=torch.float64)
+    x = torch.empty((hi - lo, d), dtype=torch.float32, device=device)
+    y = torch.empty(hi - lo, dtype=torch.float64, device=device)
+    B = DATA_BLOCK_ROWS
+    for b in range(lo // B, (hi + B - 1) // B if hi > lo else lo // B):
+        gen = torch.Generator(device=device)
+        gen.manual_seed(123_000_000 + b)
+        xb = torch.randn((B, d), generator=gen, device=device, dtype=torch.float32) / np.sqrt(d)
+        yb = torch.sin(xb @ a).double() + 0.1 * torch.randn(B, generator=gen, device=device, dtype=torch.float64)
+        s0, s1 = max(lo, b * B), min(hi, (b + 1) * B)          # global rows of this block held by the shard
+        x[s0 - lo:s1 - lo] = xb[s0 - b * B:s1 - b * B]
+        y[s0 - lo:s1 - lo] = yb[s0 - b * B:s1 - b * B]
     return x, y
+
+
+# Loss (relative residual) of the preconditioned CG solve after `steps` iterations, measured on MI355X with ONE rank:
+# (rows, dim, rffs, rank, steps) -> value.  The dataset does not depend on the number of ranks (make_shard), the
+# preconditioner and the iterates only through the summation order of the all-reduced sums (and the eigensolver's last
+# digits), so the same value holds at every N: rtol 1e-6 on one rank, 1e-5 when sums are exchanged.
+EXPECTED_FINAL_LOSS = {}
+
+
+def final_loss_check(key, loss, world_size, table=None):
+    """The timed iterations are a real solve: compare its final loss with the stored one.  Returns the object the JSON
+    line carries ({"expected", "rtol", "ok"}; ok is None when no value is stored for this configuration)."""
+    table = EXPECTED_FINAL_LOSS if table is None else table
+    if key not in table:
+        return {"expected": None, "rtol": None, "ok": None}
+    rtol = 1e-6 if world_size == 1 else 1e-5
+    ok = bool(abs(loss / table[key] - 1.0) <= rtol)          # False for NaN
+    return {"expected": table[key], "rtol": rtol, "ok": ok}
 
 
 def cpu_baseline(args, budget_s):
@@ -233,17 +267,86 @@ def conv_featgen_probe(device, nseq=8192):
     return out
 
 
-# loss (relative residual) of the preconditioned CG solve after `steps` iterations: (rows, dim, rffs, rank, steps) -> value
-EXPECTED_FINAL_LOSS = {(1_000_000, 1024, 8192, 512, 20): 0.0130151070155}
+def config_share(which, device, rows=None):
+    """One of the BASELINE configs that are not the headline, at the per-GPU share of its 8-GPU size (cfg2: whole), on
+    this GPU: randomized-Nystrom preconditioner build + CG fit to 1e-6 through the product's own entry points
+    (RandNysPreconditioner, cg_fit_lib_internal -- the calls xGPRegression.fit(mode="cg") makes).  Synthetic inputs of
+    the shape SURVEY 8(d) names; y ~ N(0,1).  Returns the timing object of the JSON line's ``configs`` entry."""
+    import numpy as np
+    import torch
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import cg_fit_lib_internal
+    g = torch.Generator(device=device).manual_seed(123)
+    sl = None
+    if which == "cfg2":      # RBF, N=1e5 d=256, 4096 RFFs, single GPU
+        n = rows or 100_000
+        d, m, rank, method, chunk = 256, 4096, 512, "srht", 8192
+        x = torch.randn(n, d, device=device, generator=g) / d ** 0.5
+        kern = make_kernel("RBF", (n, d), m, 123, device, {})
+        what = "RBF, N=%d (whole), d=256, 4096 RFFs" % n
+    elif which == "cfg4":    # Conv1d RBF, L<=512, 21 channels one-hot, 16384 RFFs; N=5e5 over 8 GPUs -> 62500 per GPU
+        n = rows or 62_500
+        L, C, m, rank, method, chunk = 512, 21, 16384, 512, "srht", 1024
+        x = torch.nn.functional.one_hot(torch.randint(0, C, (n, L), device=device, generator=g), C).to(torch.float32)
+        sl = torch.randint(64, L + 1, (n,), generator=torch.Generator().manual_seed(5)).numpy().astype(np.int32)
+        kern = make_kernel("Conv1dRBF", (n, L, C), m, 123, device, {"conv_width": 9, "averaging": "sqrt"})
+        what = "Conv1dRBF, %d sequences (1/8 of 5e5; L 64..512, 21 channels, conv_width 9), 16384 RFFs" % n
+    elif which == "cfg5":    # RBF, d=512, 32768 RFFs, rank-2048 srht_2; N=2e6 over 8 GPUs -> 250000 per GPU
+        n = rows or 250_000
+        d, m, rank, method, chunk = 512, 32768, 2048, "srht_2", 8192
+        x = torch.randn(n, d, device=device, generator=g) / d ** 0.5
+        kern = make_kernel("RBF", (n, d), m, 123, device, {})
+        what = "RBF, %d rows (1/8 of 2e6), d=512, 32768 RFFs" % n
+    else:
+        raise ValueError(which)
+    y = torch.randn(n, dtype=torch.float64, device=device, generator=g)
+    ds = build_regression_dataset(x, y, sl, chunk_size=chunk, device=device)
+    kern.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+    # small untimed build + fits first: library initialisation and first launches are not part of a build
+    nw = min(n, 4096)
+    ds_w = build_regression_dataset(x[:nw], y[:nw], None if sl is None else sl[:nw], chunk_size=chunk, device=device)
+    pre_w = RandNysPreconditioner(kern, ds_w, min(rank, 256), False, 123, method)
+    modes = (True,) if which == "cfg4" else (False, True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for cache in modes:
+            cg_fit_lib_internal(kern, ds_w, 1e-6, 5, pre_w, False, cache_features=cache)
+    del ds_w, pre_w
+    pre, t_pre = timed(lambda: RandNysPreconditioner(kern, ds, rank, False, 123, method))
+    out = {"workload": what, "rank": rank, "method": method, "precond_build_s": t_pre,
+           "achieved_ratio": float(pre.achieved_ratio), "fits": []}
+    for cache in modes:
+        t_cache = 0.0
+        if cache:
+            torch.cuda.empty_cache()          # the build's scratch goes back to the driver before the big allocation
+            _, t_cache = timed(lambda: ds.feature_cache(kern))
+        (w, niter, losses), t_fit = timed(lambda: cg_fit_lib_internal(kern, ds, 1e-6, 200, pre, False, cache_features=cache))
+        out["fits"].append({"features": "resident float32 cache" if cache else "regenerated every iteration",
+                            "iterations": int(niter), "seconds": t_fit, "ms_per_iteration": 1e3 * t_fit / niter,
+                            "feature_cache_s": t_cache if cache else None, "final_err": losses[-1]})
+    ds._zcache = None
+    del ds, pre, x, y, kern
+    torch.cuda.empty_cache()
+    return out
 
 
 def valu_only_probe(kern, ds, kern_ms, device):
-    """Times the fused matvec of this rank's shard through the VALU-only timing probe (xgpr_amd/build.py PROBE_LIB: the
+    """Times the fused matvec of this rank's shard through the VALU-only timing probe (tools/, xgpr_amd/build.py PROBE_LIB: the
     kernel's vector instruction stream with LDS traffic, barrier and prefetch compiled out; results meaningless, never
     used).  Returns {"ms", "frac"} or None when the probe library has not been built."""
     import ctypes as C
     import torch
-    path = os.path.join(ROOT, "xgpr_amd", "libxgpr_hip_valuonly_probe.so")
+    path = os.path.join(ROOT, "tools", "libxgpr_hip_valuonly_probe.so")
     if not os.path.exists(path):
         return None
     fn = C.CDLL(path).xgpr_ztz_matvec_f32
@@ -314,7 +417,7 @@ def main():
 
     n, d, m = args.rows, args.dim, args.rffs
     lo, hi = comm.shard_bounds(n)
-    x, y = make_shard(hi - lo, d, comm.rank, device)
+    x, y = make_shard(lo, hi, d, device)
     ds = build_regression_dataset(x, y, chunk_size=16384, device=device, comm=comm, already_sharded=True)
     kern = make_kernel("Matern", (n, d), m, 123, device, {"matern_nu": 5 / 2})
     kern.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
@@ -393,13 +496,9 @@ def main():
     comm.barrier()
     t1 = time.perf_counter()
     assert niter == args.steps
-    # the timed iterations are a real solve: for the default problem the loss after `steps` iterations is a stored
-    # value (measured on MI355X; the synthetic data, preconditioner and iterates are deterministic up to the summation
-    # order over ranks and the eigensolver's last digits)
-    key = (args.rows, args.dim, args.rffs, args.rank_precond, args.steps)
-    if key in EXPECTED_FINAL_LOSS and abs(losses[-1] / EXPECTED_FINAL_LOSS[key] - 1.0) > 1e-6:
-        raise RuntimeError(f"final loss {losses[-1]!r} differs from the stored {EXPECTED_FINAL_LOSS[key]!r}: the timed "
-                           "iterations did not do the work they claim")
+    # the timed iterations are a real solve: its final loss against the stored value (reported in the line; a mismatch
+    # makes the run exit non-zero AFTER the line is printed)
+    loss_check = final_loss_check((args.rows, args.dim, args.rffs, args.rank_precond, args.steps), losses[-1], comm.world_size)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if comm.through_backend:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
@@ -409,6 +508,24 @@ def main():
     kern.ztz_matvec = orig
     comm.all_reduce_ = orig_ar
     per_rank = gather_per_rank(comm, device, [1e3 * (t1 - t0) / args.steps, kern_ms, ar_ms, float(hi - lo)])
+
+    # time to tolerance of the north-star entry point's solve (xGPRegression.fit(mode="cg"): preconditioner build, then
+    # cg_fit_lib_internal's solve to 1e-6 -- xgp_regression.py's fit path, cg_fitting_toolkit.py:18-70); every rank runs it
+    comm.barrier()
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    resid = torch.zeros((m, 2, 1), dtype=torch.float64, device=device)
+    resid[:, 0, 0] = pre.get_zty() / n
+    _, tol_converged, tol_iters, tol_losses = cg.fit(ds, kern, pre, resid, maxiter=500, tol=1e-6, verbose=False)
+    torch.cuda.synchronize()
+    comm.barrier()
+    tol_s = torch.tensor([time.perf_counter() - tf0], dtype=torch.float64, device=device)
+    if comm.through_backend:
+        torch.distributed.all_reduce(tol_s, op=torch.distributed.ReduceOp.MAX)
+    fit_to_tol = {"tol": 1e-6, "converged": bool(tol_converged), "iterations": int(tol_iters), "cg_seconds": float(tol_s.item()),
+                  "precond_build_seconds": precond_build_s, "seconds": float(tol_s.item()) + precond_build_s,
+                  "final_err": tol_losses[-1], "note": "build (all rows, rank %d srht) + preconditioned CG to 1e-6, features "
+                  "regenerated on every iteration; wall clock, max over ranks" % args.rank_precond}
 
     # optional mode, reported beside the headline and never part of it: the shard's feature matrix kept
     # resident in HBM as float32 (32 KB per datapoint) and streamed on every CG iteration instead of
@@ -459,8 +576,8 @@ def main():
         kern.ztz_matvec_cached = origc
         cbytes = 4.0 * m * (hi - lo)
         ctraffic = None
-        try:   # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (profiles/r1_pmc_traffic_cached.json)
-            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
+        try:   # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (profiles/r3_pmc_traffic_cached.json; stored)
+            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
         except (OSError, KeyError, ValueError):
             pass
         cached = {"ms_per_step": 1e3 * float(tc.item()) / args.steps, "cg_iters_per_sec": args.steps / float(tc.item()),
@@ -522,6 +639,17 @@ def main():
 
     conv = conv_featgen_probe(device) if (comm.rank == 0 and args.gpus == 1) else None
 
+    valu_probe = None
+    if comm.rank == 0 and (d, m) == (1024, 8192):
+        valu_probe = valu_only_probe(kern, ds, kern_ms, device)
+
+    # the other BASELINE configs at their per-GPU shares (N = 1 only; collective-free: they run on comm SINGLE)
+    configs = None
+    if comm.rank == 0 and args.gpus == 1 and not args.no_configs and n == 1_000_000:
+        del pre, ds_pre, ds, x, y, cg
+        torch.cuda.empty_cache()
+        configs = {c: config_share(c, device) for c in ("cfg2", "cfg4", "cfg5")}
+
     if comm.rank == 0:
         n_local = hi - lo
         # HBM bytes per launch of the dominant kernel from the PMC counters: a STORED measurement (separate
@@ -560,7 +688,7 @@ def main():
                                                "frac": inst_s / peak_inst},
                                "priced": {"pipe_ms": pipe_ms, "frac": pipe_ms / kern_ms,
                                           "source": "profiles/r3_ztz3_inst_table.json x profiles/r3_valu_cost.json (stored)"},
-                               "valu_only": valu_only_probe(kern, ds, kern_ms, device)}
+                               "valu_only": valu_probe}
         except (OSError, KeyError, ValueError):
             pass
         alg_bytes = 4.0 * d * n_local                   # 4*d bytes per row, X read once
@@ -602,7 +730,9 @@ def main():
                                           "allreduce_ms_per_iter": v[2], "rows": int(v[3])} for i, v in enumerate(per_rank)],
                             "allreduce_note": "allreduce_ms_per_iter is measured by HIP events on the compute stream around the "
                                               "all-reduce of w (allreduce_path), inside the timed CG iterations"},
-            "final_loss": losses[-1],
+            "final_loss": losses[-1], "final_loss_check": loss_check,
+            "fit_to_tol": fit_to_tol,
+            "configs": configs,
             "precond_build": {"seconds": precond_build_s, "first_build_seconds": precond_first_s, "rows": n,
                               "rank": args.rank_precond, "method": "srht",
                               "flops": 2.0 * n * args.rank_precond * m,
@@ -622,6 +752,9 @@ def main():
         print(json.dumps(out))
     if comm.through_backend:
         torch.distributed.destroy_process_group()
+    if loss_check["ok"] is False:
+        raise SystemExit(f"final loss {losses[-1]!r} differs from the stored {loss_check['expected']!r} (rtol {loss_check['rtol']}): "
+                         "the timed iterations did not do the work they claim")
 
 
 if __name__ == "__main__":

@@ -14,7 +14,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 def test_one_rank_through_rccl():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update({"XGPR_DIST_FORCE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    env.update({"XGPR_DIST_FORCE": "1", "XGPR_RCCL_DIRECT": "1",        # the direct path is opt-in
+                "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-check", "--rows", "1000"]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -29,9 +30,9 @@ def test_one_rank_through_rccl():
 
 
 def test_one_rank_torch_distributed_fallback():
-    """XGPR_RCCL_DIRECT=0 keeps every collective on torch.distributed."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update({"XGPR_DIST_FORCE": "1", "XGPR_RCCL_DIRECT": "0",
+    """The default (XGPR_RCCL_DIRECT unset) keeps every collective on torch.distributed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "XGPR_RCCL_DIRECT")}
+    env.update({"XGPR_DIST_FORCE": "1",
                 "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29548", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-check", "--rows", "1000"]

@@ -17,8 +17,9 @@ LIB = os.path.join(HERE, "libxgpr_hip.so")
 # Roofline probe, NOT a product library: the same translation unit with -DXGPR_ABL_VALUONLY, in which the fused CG
 # matvec keeps its vector instruction stream but has its LDS traffic, workgroup barrier and prefetch DMA compiled
 # out (its results are meaningless).  bench.py times it beside the real kernel: the ratio is how much of the kernel's
-# time its own vector instructions need at the kernel's occupancy.  Nothing under xgpr_amd/ loads it.
-PROBE_LIB = os.path.join(HERE, "libxgpr_hip_valuonly_probe.so")
+# time its own vector instructions need at the kernel's occupancy.  It is built into tools/ (not into the product
+# package); nothing under xgpr_amd/ loads it.
+PROBE_LIB = os.path.join(HERE, "..", "tools", "libxgpr_hip_valuonly_probe.so")
 
 # -ffp-contract=off: the butterflies / Rademacher multiplies must round like the reference's
 # scalar code (see the header comment of csrc/xgpr_hip.hip).

@@ -30,7 +30,18 @@
 #include <string.h>
 #include <string>
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>          // types only: the library is resolved at run time (xgpr_rccl_load), never linked
+#else
+// No RCCL development headers on this install: the handful of ABI-stable NCCL types the dlsym'ed entry points use
+// (rccl.h: ncclComm_t opaque, 128-byte id, ncclSuccess = 0, ncclSum = 0, ncclFloat64 = 8).
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat64 = 8 } ncclDataType_t;
+#endif
 
 #include "../../include/xgpr_hip.h"
 

@@ -13,9 +13,12 @@ chains it to the compute stream with an event on each side.  For the float64 sum
 iteration: latency-bound) ``Comm`` instead owns a second RCCL communicator, created through the C ABI
 (``xgpr_rccl_comm_init``; the 128-byte id travels through torch.distributed's own channel) and calls
 ``xgpr_allreduce_sum_f64``: ``ncclAllReduce`` enqueued on the CURRENT stream, directly behind the kernel that wrote
-the partial sum.  ``XGPR_RCCL_DIRECT=0`` keeps everything on torch.distributed; the direct path is also dropped (on all
-ranks together) if its set-up or its self test -- a sum of ones -- fails.
+the partial sum.  The direct path is OPT-IN (``XGPR_RCCL_DIRECT=1``): until a run with two or more ranks on real
+hardware has confirmed it (bench.py reports ``direct_equals_torch_allreduce`` and the final loss when it is on), every
+collective stays on torch.distributed.  When requested it is still dropped, on all ranks together, if its set-up or its
+self test -- a sum of ones -- fails, and the communicator is destroyed (``Comm.close``, also at interpreter exit).
 """
+import atexit
 import ctypes
 import os
 
@@ -32,11 +35,25 @@ class Comm:
         # there is nobody to exchange with, so that communicator set-up and stream ordering are exercised on one GPU
         self.through_backend = through_backend or world_size > 1
         self._rccl = None                 # ncclComm_t of the direct path (enable_direct_rccl)
+        self._rccl_lib = None             # the C-ABI library it was created through
+
+    def _direct_requested(self):
+        return (self.through_backend and os.environ.get("XGPR_RCCL_DIRECT", "0") == "1"
+                and dist.get_backend(self.group) == "nccl")
+
+    @staticmethod
+    def _load_rccl_entry_points():
+        """The C-ABI library with RCCL resolved (xgpr_rccl_load), or raises."""
+        from xgpr_amd import _lib          # (absolute: bench.py --dist-check loads this file by path)
+        lib = _lib.load()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _lib.check(lib.xgpr_rccl_load((path if os.path.exists(path) else "librccl.so").encode()))
+        return lib
 
     def enable_direct_rccl(self, device):
         """Create this rank's communicator for the on-stream all-reduce (module docstring).  Collective: every rank
         calls it.  Returns True when the direct path is in use."""
-        if not self.through_backend or os.environ.get("XGPR_RCCL_DIRECT", "1") == "0" or dist.get_backend(self.group) != "nccl":
+        if not self._direct_requested():
             return False
         def all_agree(ok):               # every rank keeps or drops the direct path together
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
@@ -44,24 +61,23 @@ class Comm:
             return int(flag.item()) == 1
 
         # Every torch.distributed collective below is reached by every rank whatever happened locally (a rank that
-        # failed a local step still takes part, with "not ok"), so that a one-sided failure cannot leave the others waiting.
+        # failed a local step still takes part, with "not ok"), and no rank issues a collective on the NEW communicator
+        # before all ranks have agreed that every one of them holds it -- a one-sided failure cannot leave the others waiting.
         lib = None
         try:
-            from xgpr_amd import _lib          # (absolute: bench.py --dist-check loads this file by path)
-            lib = _lib.load()
-            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-            _lib.check(lib.xgpr_rccl_load((path if os.path.exists(path) else "librccl.so").encode()))
+            lib = self._load_rccl_entry_points()
         except (RuntimeError, OSError, AttributeError, ImportError):
             lib = None
         if not all_agree(1 if lib is not None else 0):
             return False
+        self._rccl_lib = lib
         box = [None]
         if self.rank == 0:
             try:
                 ident = ctypes.create_string_buffer(128)
-                _lib.check(lib.xgpr_rccl_unique_id(ctypes.cast(ident, ctypes.c_void_p)))
-                box = [ident.raw]
-            except RuntimeError:
+                if lib.xgpr_rccl_unique_id(ctypes.cast(ident, ctypes.c_void_p)) == 0:
+                    box = [ident.raw]
+            except (RuntimeError, OSError, AttributeError):
                 box = [None]
         dist.broadcast_object_list(box, src=0, group=self.group)
         if box[0] is None:
@@ -70,24 +86,46 @@ class Comm:
         try:
             ident = ctypes.create_string_buffer(box[0], 128)
             handle = ctypes.c_void_p()
-            _lib.check(lib.xgpr_rccl_comm_init(ctypes.cast(ctypes.byref(handle), ctypes.c_void_p), self.world_size,
-                                               ctypes.cast(ident, ctypes.c_void_p), self.rank))
-            self._rccl = handle
+            if lib.xgpr_rccl_comm_init(ctypes.cast(ctypes.byref(handle), ctypes.c_void_p), self.world_size,
+                                       ctypes.cast(ident, ctypes.c_void_p), self.rank) != 0:
+                ok = 0
+            else:
+                self._rccl = handle
+        except (RuntimeError, OSError, AttributeError):
+            ok = 0
+        if not all_agree(ok):            # somebody has no communicator: nobody uses theirs
+            self.close()
+            return False
+        ok = 1
+        try:
             probe = torch.ones(8, dtype=torch.float64, device=device)
             self._direct_sum(probe)
-            torch.cuda.synchronize(device)
+            if probe.is_cuda:
+                torch.cuda.synchronize(device)
             if not bool((probe == float(self.world_size)).all()):
                 ok = 0
         except (RuntimeError, OSError, AttributeError):
             ok = 0
         if not all_agree(ok):
-            self._rccl = None
+            self.close()
+        else:
+            atexit.register(self.close)
         return self._rccl is not None
 
+    def close(self):
+        """Destroy the direct communicator (if any); the sums go back to torch.distributed.  Local, idempotent."""
+        handle, self._rccl = self._rccl, None
+        if handle is not None:
+            try:
+                self._rccl_lib.xgpr_rccl_comm_destroy(handle)
+            except (RuntimeError, OSError, AttributeError):
+                pass
+
     def _direct_sum(self, tensor):
-        from xgpr_amd import _lib
-        _lib.check(_lib.load().xgpr_allreduce_sum_f64(self._rccl, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),
-                                                      ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)))
+        rc = self._rccl_lib.xgpr_allreduce_sum_f64(self._rccl, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),
+                                                   ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("xgpr_allreduce_sum_f64 failed: " + self._rccl_lib.xgpr_last_error().decode())
 
     @property
     def direct_rccl(self):

@@ -29,7 +29,14 @@ def gram_route(dataset, kernel, msub):
     if hasattr(kernel, "fused_ok") and kernel.fused_ok() and hasattr(kernel, "fill_feature_cache"):
         return False
     if hasattr(kernel, "cache_ok") and kernel.cache_ok() and hasattr(kernel, "build_feature_cache"):
-        return True
+        # the resident route pins n_local x M x 4 bytes on the dataset: taken only when the cache is already there or
+        # fits in free HBM with the same headroom rule the solver uses (cg._resolve_cache_mode); otherwise the bounded
+        # chunked float64 formulation
+        from .cg import _resolve_cache_mode
+        held = getattr(dataset, "_zcache_key", None) == (id(kernel), float(kernel.hyperparams[1])) \
+            and getattr(dataset, "_zcache", None) is not None
+        if held or _resolve_cache_mode("auto", kernel, dataset, block=False):
+            return True
     return None
 
 
