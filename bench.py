@@ -526,6 +526,34 @@ def main():
                   "precond_build_seconds": precond_build_s, "seconds": float(tol_s.item()) + precond_build_s,
                   "final_err": tol_losses[-1], "note": "build (all rows, rank %d srht) + preconditioned CG to 1e-6, features "
                   "regenerated on every iteration; wall clock, max over ranks" % args.rank_precond}
+    # the same solve the way the product's cg_fit_lib_internal runs it by default (cache_features="auto": the shard's
+    # float32 feature matrix resident in HBM when it fits, generated once and streamed) -- reported beside, never the headline
+    from xgpr_amd.cg import cg_fit_lib_internal
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cg_fit_lib_internal(kern, ds, 1e-6, 3, pre, False, cache_features="auto")      # first launches / first allocation, untimed
+    ds._zcache = None                    # the cache is generated again inside the timed region (the allocator keeps the block)
+    ds._zcache_key = None
+    comm.barrier()
+    torch.cuda.synchronize()
+    ta0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, auto_iters, auto_losses = cg_fit_lib_internal(kern, ds, 1e-6, 500, pre, False, cache_features="auto")
+    torch.cuda.synchronize()
+    comm.barrier()
+    auto_s = torch.tensor([time.perf_counter() - ta0], dtype=torch.float64, device=device)
+    if comm.through_backend:
+        torch.distributed.all_reduce(auto_s, op=torch.distributed.ReduceOp.MAX)
+    fit_to_tol["product_default"] = {"iterations": int(auto_iters), "cg_seconds": float(auto_s.item()),
+                                     "seconds": float(auto_s.item()) + precond_build_s, "final_err": auto_losses[-1],
+                                     "note": "cg_fit_lib_internal(cache_features='auto'): resident float32 features when they fit; "
+                                             "the feature-generation pass that fills the cache is inside cg_seconds, its first "
+                                             "hipMalloc (0.5-0.9 s of page scrubbing, once per process) is not"}
+    ds._zcache = None
+    ds._zcache_key = None
+    torch.cuda.empty_cache()
 
     # optional mode, reported beside the headline and never part of it: the shard's feature matrix kept
     # resident in HBM as float32 (32 KB per datapoint) and streamed on every CG iteration instead of

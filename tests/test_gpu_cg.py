@@ -234,6 +234,27 @@ def test_batched_rhs_cg_matches_oracle(oracle):
     assert rel(xk, xref) < 1e-6
 
 
+def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_faster():
+    """cache_features="auto": one right-hand side and a single feature pass (num_freqs <= 8192) regenerates -- the
+    fused kernel is at least as fast as the HBM stream of the cache; two feature passes (num_freqs > 8192), a block of
+    right-hand sides, or a convolution kernel keep the float32 features resident (when they fit)."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import _resolve_cache_mode
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((256, 64)).astype(np.float32)
+    ds = build_regression_dataset(x, rng.standard_normal(256), chunk_size=128, device=DEV)
+    small = make_kernel("RBF", x.shape, 4096, 123, DEV, {})
+    wide = make_kernel("RBF", x.shape, 32768, 123, DEV, {})
+    for k in (small, wide):
+        k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+    assert small.cache_ok() and not small.cache_pays() and wide.cache_pays()
+    assert _resolve_cache_mode("auto", small, ds) is False
+    assert _resolve_cache_mode("auto", wide, ds) is True
+    assert _resolve_cache_mode("auto", small, ds, block=True) is True
+    assert _resolve_cache_mode(True, small, ds) is True and _resolve_cache_mode(False, wide, ds) is False
+
+
 def test_cg_with_resident_feature_cache_matches_regenerating_cg():
     """cache_features=True (Z kept in HBM as float32, streamed each iteration) gives the same solve as
     the default (features regenerated each iteration): iteration counts within one at tol 1e-8, weights to 1e-7."""

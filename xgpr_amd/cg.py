@@ -383,7 +383,8 @@ class ConjugateGrad:
 
 
 def _resolve_cache_mode(cache_features, kernel, dataset, block=False):
-    """"auto": keep Z resident when the kernel supports it and the float32 cache of this shard fits
+    """"auto": keep Z resident when the kernel supports it, when streaming it is faster than regenerating it
+    (``kernel.cache_pays``; always for a block of right-hand sides) and the float32 cache of this shard fits
     comfortably in free HBM (it then needs cache + 2 GB with 1.5x headroom).  ``block``: the solve has
     a block of right-hand sides (matrix-core matvec), which caches under ``block_ok``."""
     if cache_features != "auto":
@@ -391,6 +392,8 @@ def _resolve_cache_mode(cache_features, kernel, dataset, block=False):
     supported = getattr(kernel, "block_ok" if block else "cache_ok", None)
     if supported is None or not supported() or torch.device(kernel.device).type != "cuda":
         return False
+    if not block and hasattr(kernel, "cache_pays") and not kernel.cache_pays():
+        return False          # one right-hand side, single-pass fused kernel: regenerating is at least as fast (kernels.py)
     free, _total = torch.cuda.mem_get_info(torch.device(kernel.device))
     return 1.5 * dataset.feature_cache_bytes(kernel) + 2e9 < free
 
