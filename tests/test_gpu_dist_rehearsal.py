@@ -40,3 +40,24 @@ def test_one_rank_torch_distributed_fallback():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["allreduce_path"].startswith("torch.distributed") and out["n_ranks_seen"] == 1
+
+
+def test_whole_bench_through_the_backend_with_one_rank():
+    """The driver's launch line, every collective of the run issued through RCCL (one rank): data generation, the
+    preconditioner's all-reduces, the timed iterations, the solve to tolerance and the reporting all complete and the
+    line carries the distributed fields."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "XGPR_RCCL_DIRECT")}
+    env.update({"XGPR_DIST_FORCE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rows", "40000", "--steps", "4",
+           "--warmup", "1", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    dist = out["distributed"]
+    assert dist["backend"] == "nccl" and dist["n_ranks_seen"] == 1 and dist["allreduce_path"].startswith("torch.distributed")
+    assert len(dist["per_rank"]) == 1 and dist["per_rank"][0]["rows"] == 40000 and dist["per_rank"][0]["allreduce_ms_per_iter"] > 0
+    assert out["steps"] == 4 and out["value"] > 0 and out["fit_to_tol"]["converged"] is True
+    assert out["final_loss_check"]["ok"] is None          # no stored value for this size
