@@ -196,6 +196,27 @@ int xgpr_cg_step1_f64(double *w, const double *p, double *x, const double *r, do
 int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *p, double *p_next,
                       double *scal, long M, double stop_tol, void *stream);
 
+/* The same two steps for a block of k right-hand sides (GPU_ConjugateGrad.fit with k > 1,
+ * src/xGPR/fitting_toolkit/cg_tools.py:121-141 / :255-274; the approximate NMLL's 26-column solve,
+ * src/xGPR/xgp_regression.py:338-367): every vector is float64 [M, k] row-major, as the block matvec takes and returns
+ * them.  Per column j: rz[j] carries r.z from step 1 to step 2; init_norm[j] = |r_0[:, j]|; alpha_out[j], beta_out[j],
+ * err_out[j] are this iteration's rows of the caller's [iterations, k] tables (err_out may be pinned host memory, written
+ * by the device and followed by a system-scope fence).  k <= 32.  Each step is two launches over row blocks (per-block
+ * partial dot products in the workspace, added in block order by every workgroup of the second launch). */
+size_t xgpr_cg_block_workspace_bytes(long M, long k);
+int xgpr_cg_step1_block_f64(double *w, const double *p, double *x, const double *r, double *r_next, const double *z,
+                            double *rz, double *alpha_out, double *err_out, const double *init_norm, double lam2,
+                            long M, long k, void *workspace, size_t workspace_bytes, void *stream);
+int xgpr_cg_step2_block_f64(const double *r_next, const double *z_next, const double *p, double *p_next, const double *rz,
+                            double *beta_out, long M, long k, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The first product of RandNysPreconditioner.batch_matvec for a block of right-hand sides
+ * (src/xGPR/preconditioners/rand_nys_preconditioners.py:68, `self.u_mat.T @ xvec`): t_out [rank, k] = U^T R with
+ * U [M, rank], R [M, k] float64 row-major, k <= 32; per-row-block partial sums in the workspace, added in block order. */
+size_t xgpr_precond_utr_block_workspace_bytes(long M, long rank, long k);
+int xgpr_precond_utr_block_f64(const double *u, const double *r, double *t_out, long M, long rank, long k,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- RandNysPreconditioner.batch_matvec for one right-hand side
  * (src/xGPR/preconditioners/rand_nys_preconditioners.py:66-72):
  *   z = U (inv_eig * prefactor .* U^T r) + (r - U U^T r),   U [M, rank] float64 row-major. */

@@ -215,3 +215,71 @@ def test_g15_crude_tuning_vs_reference():
     # the acquisitions themselves may differ (a score that differs in the third decimal changes the surrogate);
     # the optimum found must be as good and in the same place
     assert np.abs(hp - g["crude_hparams"]).max() < 0.2
+
+
+@pytest.mark.parametrize("m,k,with_pre", [(512, 26, True), (2100, 3, False), (12288, 26, True), (4096, 2, True)])
+def test_block_device_solve_equals_the_generic_loop(m, k, with_pre, monkeypatch):
+    """The batched solve with its vector updates in two kernels per iteration (hipCGStep1Block / hipCGStep2Block, errors
+    read one iteration behind) against the generic loop of torch operations: same iteration count, alphas / betas /
+    iterates to rounding (the two forms differ in the summation order of the dot products and in the algebraic form
+    of the preconditioner apply), with and without a preconditioner, M below and above one batch of the kernels, in
+    both return conventions of ``fit``."""
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import ConjugateGrad
+    rng = np.random.default_rng(m + k)
+    n, d = 900, 40
+    x = rng.standard_normal((n, d)).astype(np.float32) / np.sqrt(d)
+    y = np.sin(x @ rng.standard_normal(d)) + 0.1 * rng.standard_normal(n)
+    ds = build_regression_dataset(x, y, chunk_size=300, device=DEV)
+    kern = make_kernel("RBF", x.shape, m, 123, DEV, {})
+    # (without a preconditioner a larger ridge keeps the recurrence from amplifying the 1e-16 differences between the two
+    # forms within the compared iterations: 900 rows against up to 12288 features is rank-deficient at lambda = 0.4)
+    kern.set_hyperparams(np.array([0.4 if with_pre else 4.0, 1.1]), logspace=False)
+    pre = RandNysPreconditioner(kern, ds, 48, False, 123, "srht") if with_pre else None
+    rhs = torch.from_numpy(rng.standard_normal((m, k))).to(DEV)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ConjugateGrad, "BLOCK_DEVICE_SOLVE", fused)
+        for nm in (True, False):
+            resid = torch.zeros((m, 2, k), dtype=torch.float64, device=DEV)
+            resid[:, 0, :] = rhs
+            out[(fused, nm)] = ConjugateGrad(cache_features=True).fit(ds, kern, pre, resid, 400, 1e-8, False, nmll_settings=nm)
+    xa, al_a, be_a = out[(True, True)]
+    xb, al_b, be_b = out[(False, True)]
+    # (iteration counts: equal, or one apart when the last error sits on the tolerance -- the two forms round differently)
+    assert abs(al_a.shape[0] - al_b.shape[0]) <= 1 and al_a.shape[1] == al_b.shape[1] == k - 1
+    assert be_a.shape == al_a.shape and be_b.shape == al_b.shape
+    # Once a column's residual reaches its rounding floor its alpha / beta are quotients of noise (measured: the two forms
+    # agree to 1e-16 for five iterations, then 1e-11, 1e-6, 0.2 as the 3-column solve at lambda = 4 converges): compare
+    # the iterations in which every residual is still resolved
+    early = min(al_a.shape[0], al_b.shape[0], 5)
+    assert rel(al_a[:early], al_b[:early].cpu().numpy()) < 1e-9 and rel(be_a[:early], be_b[:early].cpu().numpy()) < 1e-8
+    assert rel(xa, xb.cpu().numpy()) < 1e-7
+    xc, conv_c, nit_c, loss_c = out[(True, False)]
+    xd, conv_d, nit_d, loss_d = out[(False, False)]
+    assert conv_c and conv_d and nit_c == al_a.shape[0] and nit_d == al_b.shape[0]
+    assert len(loss_c) == nit_c and len(loss_d) == nit_d
+    assert rel(xc, xd.cpu().numpy()) < 1e-7 and np.allclose(loss_c[:early], loss_d[:early], rtol=1e-6)
+    assert torch.equal(xc, xa)                         # the two return conventions are one solve
+
+
+@pytest.mark.parametrize("m,rank,k", [(8192, 512, 26), (2100, 48, 3), (1000, 513, 32), (64, 7, 1), (12288, 1030, 9)])
+def test_utr_block_kernel_equals_the_product(m, rank, k):
+    """hipPrecondUtRBlock (U^T R for a block of right-hand sides, the first product of
+    rand_nys_preconditioners.py:66-72) against torch's float64 product; odd ranks, more columns than one pass of the
+    kernel's 512, row counts that do not divide the blocks."""
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    g = torch.Generator(device=DEV).manual_seed(m + rank + k)
+    u = torch.randn(m, rank, dtype=torch.float64, device=DEV, generator=g)
+    r = torch.randn(m, k, dtype=torch.float64, device=DEV, generator=g)
+    t = torch.full((rank, k), float("nan"), dtype=torch.float64, device=DEV)
+    ext.hipPrecondUtRBlock(u, r, t)
+    ref = u.T @ r
+    assert float((t - ref).abs().max()) <= 1e-12 * float(ref.abs().max()) * np.sqrt(m)
+    t2 = torch.empty_like(t)
+    ext.hipPrecondUtRBlock(u, r, t2)
+    assert torch.equal(t, t2)                           # fixed summation order
+    with pytest.raises(RuntimeError):
+        ext.hipPrecondUtRBlock(u, torch.zeros(m, 33, dtype=torch.float64, device=DEV), torch.zeros(rank, 33, dtype=torch.float64, device=DEV))

@@ -39,6 +39,9 @@ SIGNATURES = {
     "xgpr_zty_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_cg_step1_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _l, _d, _vp, _vp],
     "xgpr_cg_step2_f64": [_vp, _vp, _vp, _vp, _vp, _l, _d, _vp],
+    "xgpr_precond_utr_block_f64": [_vp, _vp, _vp, _l, _l, _l, _vp, _sz, _vp],
+    "xgpr_cg_step1_block_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _l, _l, _vp, _sz, _vp],
+    "xgpr_cg_step2_block_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _vp, _sz, _vp],
     "xgpr_precond_apply_f64": [_vp, _vp, _d, _vp, _vp, _l, _l, _vp, _sz, _vp],
     "xgpr_rbf_feature_cache_f32": [_vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _vp, _sz, _vp],
     "xgpr_zcache_matvec_f32": [_vp, _vp, _vp, _l, _l, _i, _vp, _sz, _vp],
@@ -61,6 +64,8 @@ SIZE_FUNCS = {
     "xgpr_sorf_workspace_bytes": [_l, _l, _i],
     "xgpr_conv_workspace_bytes": [_l, _l, _i, _l],
     "xgpr_precond_apply_workspace_bytes": [_l],
+    "xgpr_precond_utr_block_workspace_bytes": [_l, _l, _l],
+    "xgpr_cg_block_workspace_bytes": [_l, _l],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
     "xgpr_zcache_block_workspace_bytes": [_l, _l, _l],
     "xgpr_srht_sample_workspace_bytes": [_l],

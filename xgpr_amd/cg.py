@@ -55,8 +55,9 @@ class ConjugateGrad:
         self._bws = None
         self._zwin = None
 
-    def _matvec(self, dataset, kernel, vec, matvec):
-        """cg_tools.py:173-200 (regression branch): matvec <- (Z^T Z + lambda^2) vec."""
+    def _matvec(self, dataset, kernel, vec, matvec, add_ridge=True):
+        """cg_tools.py:173-200 (regression branch): matvec <- (Z^T Z + lambda^2) vec (``add_ridge=False``: the
+        caller's vector-update kernel adds lambda^2 vec)."""
         matvec.zero_()
         # k <= 2 right-hand sides: one fused pass per column (Z never written).  More columns (the
         # NMLL probes, k = 26): the two contractions [n x M][M x k], [M x n][n x k] run on the
@@ -75,9 +76,11 @@ class ConjugateGrad:
                 z = kernel.transform_x(x, lengths)
                 matvec += z.T @ (z @ vec)
         self.comm.all_reduce_(matvec)
-        matvec += kernel.get_lambda() ** 2 * vec
+        if add_ridge:
+            matvec += kernel.get_lambda() ** 2 * vec
 
     BLOCK_KERNELS = True                # False: chunked float64 Z + library GEMMs (kept for timing comparisons)
+    BLOCK_DEVICE_SOLVE = True           # False: the generic loop of torch operations for k > 1 (tests compare the two)
     BLOCK_WINDOW_BYTES = 8 << 30        # scratch for regenerated float32 feature rows (a window fills the GPU twice over)
 
     def _block_ws(self, nrows, kernel, k, dev):
@@ -232,6 +235,95 @@ class ConjugateGrad:
                 converged = True
         return x_k, converged, done, losses
 
+    def _fit_block_device(self, dataset, kernel, preconditioner, resid, maxiter, tol, verbose, nmll_settings):
+        """The batched solve (k > 1 right-hand sides: the approximate NMLL's probes, cg_tools.py:121-141 / :255-274) with
+        its vector updates in two kernels per iteration (hipCGStep1Block / hipCGStep2Block: one workgroup per column,
+        alpha / beta / err written straight into [iterations, k] tables) and the preconditioner as two products,
+        z = r + (U diag(inv_eig * prefactor - 1)) (U^T r).  Same recurrences, lagging error and iteration count as
+        ``fit``'s generic loop, which issued ~30 small launches and one host synchronisation per iteration (0.5 ms --
+        as much as the block matvec itself on a 32 768-row shard); the host reads the errors one iteration behind from
+        pinned memory, as in the one-column solve."""
+        from . import xgpr_hip_rfgen_ext as ext
+        dev = resid.device
+        m, _, k = resid.shape
+        f64 = dict(dtype=torch.float64, device=dev)
+        r = [resid[:, 0, :].contiguous(), torch.empty((m, k), **f64)]
+        z = [torch.empty((m, k), **f64), torch.empty((m, k), **f64)]
+        p = [torch.empty((m, k), **f64), torch.empty((m, k), **f64)]
+        x_k = torch.zeros((m, k), **f64)
+        w = torch.zeros((m, k), **f64)
+        rz = torch.zeros(k, **f64)
+        init_norms = torch.linalg.norm(r[0], dim=0).contiguous()
+        alphas = torch.zeros((maxiter, k), **f64)
+        betas = torch.zeros((maxiter, k), **f64)
+        lam2 = float(kernel.get_lambda()) ** 2
+        cws = torch.empty(ext.cg_block_workspace_bytes(m, k), dtype=torch.uint8, device=dev)
+        if preconditioner is not None:
+            u_mat = preconditioner.u_mat
+            u_scaled = u_mat * (preconditioner.inv_eig * preconditioner.prefactor - 1.0)[None, :]
+            u_t = u_mat.T
+            utr = torch.empty((u_mat.shape[1], k), **f64)
+            own_utr = k <= ext.PRECOND_UTR_BLOCK_MAX_K
+            if own_utr:
+                uws = torch.empty(ext.precond_utr_block_workspace_bytes(m, u_mat.shape[1], k), dtype=torch.uint8, device=dev)
+
+        def precond(src, dst):
+            if preconditioner is None:
+                dst.copy_(src)
+            else:
+                if own_utr:
+                    ext.hipPrecondUtRBlock(u_mat, src, utr, uws)
+                else:
+                    torch.mm(u_t, src, out=utr)
+                torch.addmm(src, u_scaled, utr, out=dst)
+
+        precond(r[0], z[0])
+        p[0].copy_(z[0])
+        err_host = torch.full((maxiter, k), -1.0, dtype=torch.float64).pin_memory()
+        err_np = err_host.numpy()
+        losses, converged = [], False
+        cur, nxt = 0, 1
+        done = checked = 0
+        last_err = float("inf")
+
+        def read_err(i):
+            t0 = time.perf_counter()
+            while (err_np[i] < 0.0).any():                  # errors are >= 0 (NaN also ends the wait)
+                if time.perf_counter() - t0 > 0.05:         # long matvec (or no coherent view): wait on the stream
+                    torch.cuda.current_stream(dev).synchronize()
+                    break
+            if (err_np[i] < 0.0).any():
+                raise RuntimeError("CG errors of iteration %d never reached the host" % i)
+            losses.append(float(err_np[i, 0]))
+            return float(err_np[i].max()) if not bool((err_np[i] != err_np[i]).any()) else float("nan")
+
+        for niter in range(maxiter):
+            if checked < done and last_err < 100.0 * tol:
+                last_err = read_err(checked); checked += 1
+                if last_err < tol:
+                    converged = True
+                    break
+            self._matvec(dataset, kernel, p[cur], w, add_ridge=False)
+            if checked < done:
+                last_err = read_err(checked); checked += 1
+                if last_err < tol:
+                    converged = True
+                    break
+            ext.hipCGStep1Block(w, p[cur], x_k, r[cur], r[nxt], z[cur], rz, alphas[niter], err_host[niter], init_norms, lam2, cws)
+            precond(r[nxt], z[nxt])
+            ext.hipCGStep2Block(r[nxt], z[nxt], p[cur], p[nxt], rz, betas[niter], cws)
+            done += 1
+            cur, nxt = nxt, cur
+            if niter % 5 == 0 and verbose and self.comm.rank == 0:
+                print(f"{niter} iterations complete.")
+        while checked < done:
+            last_err = read_err(checked); checked += 1
+            if last_err < tol:
+                converged = True
+        if nmll_settings:
+            return x_k, alphas[:done, 1:].clone(), betas[:done, 1:].clone()
+        return x_k, converged, done, losses
+
     # ---- launch-bound solves: the iteration as a HIP graph (OFF by default -- measured slower, see below).
     # One CG iteration is 8-9 dependent kernels; on a small shard they take a few microseconds each and the
     # iteration costs ~70 us whatever the arithmetic.  Here the iteration (matvec, step 1, preconditioner,
@@ -321,6 +413,9 @@ class ConjugateGrad:
                 and (kernel.fused_ok() or self._use_cache(kernel))
                 and (preconditioner is None or hasattr(preconditioner, "u_mat"))):
             return self._fit_one_rhs_device(dataset, kernel, preconditioner, resid, maxiter, tol, verbose, trace)
+        if (self.BLOCK_DEVICE_SOLVE and 1 < resid.shape[2] <= 32 and dev.type == "cuda" and trace is None
+                and (preconditioner is None or hasattr(preconditioner, "u_mat"))):
+            return self._fit_block_device(dataset, kernel, preconditioner, resid, maxiter, tol, verbose, nmll_settings)
         converged = False
         target = resid[:, 0, :].clone()
         init_norms = torch.linalg.norm(target, dim=0)

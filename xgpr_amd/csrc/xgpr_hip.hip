@@ -239,6 +239,70 @@ int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *
     return 0;
 }
 
+namespace {
+constexpr long UTRB_MAX_BLOCKS = 128;
+long utrb_blocks(long M) { const long b = (M + 63) / 64; return b < UTRB_MAX_BLOCKS ? (b > 0 ? b : 1) : UTRB_MAX_BLOCKS; }
+}  // namespace
+size_t xgpr_precond_utr_block_workspace_bytes(long M, long rank, long k) {
+    return (size_t)utrb_blocks(M) * (size_t)rank * (size_t)k * sizeof(double);
+}
+int xgpr_precond_utr_block_f64(const double *u, const double *r, double *t_out, long M, long rank, long k,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (M <= 0 || rank <= 0 || k <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (k > UTRB_KMAX) return fail(XGPR_ERR_UNSUPPORTED, "U^T R block kernel takes at most 32 right-hand sides");
+    if (!workspace || workspace_bytes < xgpr_precond_utr_block_workspace_bytes(M, rank, k) || !aligned16(workspace))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_precond_utr_block_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    const long nb = utrb_blocks(M);
+    const long rows_per = (M + nb - 1) / nb;
+    double *part = reinterpret_cast<double *>(workspace);
+#define UTRB_LAUNCH(KP) hipLaunchKernelGGL((precond_utr_block_kernel<KP>), dim3((unsigned)nb), dim3(256), 0, st, u, r, part, M, rank, (int)k, rows_per)
+    if (k <= 4) UTRB_LAUNCH(4); else if (k <= 8) UTRB_LAUNCH(8); else if (k <= 16) UTRB_LAUNCH(16);
+    else if (k <= 28) UTRB_LAUNCH(28); else UTRB_LAUNCH(32);
+#undef UTRB_LAUNCH
+    HIP_TRY(hipGetLastError(), "precond_utr_block_kernel launch");
+    const long total = rank * k;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, t_out, total, nb);
+    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    return 0;
+}
+
+size_t xgpr_cg_block_workspace_bytes(long M, long k) {
+    const long nblk = (M + CGBLK_ROWS - 1) / CGBLK_ROWS;
+    return (size_t)(nblk > 0 ? nblk : 1) * 3 * (size_t)(k > 0 ? k : 1) * sizeof(double);
+}
+int xgpr_cg_step1_block_f64(double *w, const double *p, double *x, const double *r, double *r_next, const double *z,
+                            double *rz, double *alpha_out, double *err_out, const double *init_norm, double lam2,
+                            long M, long k, void *workspace, size_t workspace_bytes, void *stream) {
+    if (M <= 0 || k <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (k > CGBLK_KMAX) return fail(XGPR_ERR_UNSUPPORTED, "block CG steps take at most 32 right-hand sides");
+    if (!workspace || workspace_bytes < xgpr_cg_block_workspace_bytes(M, k))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_cg_block_workspace_bytes)");
+    const unsigned nblk = (unsigned)((M + CGBLK_ROWS - 1) / CGBLK_ROWS);
+    double *part = reinterpret_cast<double *>(workspace);
+    hipLaunchKernelGGL(cg_step1a_block_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, w, p, r, z, part, lam2, M, (int)k);
+    HIP_TRY(hipGetLastError(), "cg_step1a_block_kernel launch");
+    hipLaunchKernelGGL(cg_step1b_block_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, w, p, x, r, r_next, part, rz,
+                       alpha_out, err_out, init_norm, M, (int)k);
+    HIP_TRY(hipGetLastError(), "cg_step1b_block_kernel launch");
+    return 0;
+}
+int xgpr_cg_step2_block_f64(const double *r_next, const double *z_next, const double *p, double *p_next, const double *rz,
+                            double *beta_out, long M, long k, void *workspace, size_t workspace_bytes, void *stream) {
+    if (M <= 0 || k <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (k > CGBLK_KMAX) return fail(XGPR_ERR_UNSUPPORTED, "block CG steps take at most 32 right-hand sides");
+    if (!workspace || workspace_bytes < xgpr_cg_block_workspace_bytes(M, k))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_cg_block_workspace_bytes)");
+    const unsigned nblk = (unsigned)((M + CGBLK_ROWS - 1) / CGBLK_ROWS);
+    double *part = reinterpret_cast<double *>(workspace);
+    hipLaunchKernelGGL(cg_step2a_block_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, r_next, z_next, part, M, (int)k);
+    HIP_TRY(hipGetLastError(), "cg_step2a_block_kernel launch");
+    hipLaunchKernelGGL(cg_step2b_block_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, z_next, p, p_next, part, rz,
+                       beta_out, M, (int)k);
+    HIP_TRY(hipGetLastError(), "cg_step2b_block_kernel launch");
+    return 0;
+}
+
 size_t xgpr_precond_apply_workspace_bytes(long rank) { return (size_t)(PRE_BLOCKS + 1) * rank * sizeof(double); }
 int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefactor, const double *r, double *z,
                            long M, long rank, void *workspace, size_t workspace_bytes, void *stream) {

@@ -455,6 +455,70 @@ def hipCGStep2(r_next, z_next, p, p_next, scal, stop_tol=0.0):
         C.c_void_p(p_next.data_ptr()), C.c_void_p(scal.data_ptr()), r_next.shape[0], float(stop_tol), _stream()))
 
 
+def _blk(t, name, k=None):
+    _dev(t, name, torch.float64, 2)
+    if k is not None and t.shape[1] != k:
+        raise TypeError(f"{name}: expected [M, {k}]")
+    return C.c_void_p(t.data_ptr())
+
+
+CG_BLOCK_MAX_K = 32
+
+
+def cg_block_workspace_bytes(m, k):
+    return int(_LIB.xgpr_cg_block_workspace_bytes(m, k))
+
+
+def hipCGStep1Block(w, p, x, r, r_next, z, rz, alpha_out, err_out, init_norm, lam2, workspace):
+    """cg_tools.py:256-265 for a block of k <= 32 right-hand sides, all [M, k] row-major (see include/xgpr_hip.h).
+    ``rz``, ``alpha_out``, ``init_norm``: float64 [k] on the device; ``err_out``: float64 [k], device or pinned host."""
+    m, k = w.shape
+    ptrs = [_blk(t, n, k) for t, n in ((w, "w"), (p, "p"), (x, "x"), (r, "r"), (r_next, "r_next"), (z, "z"))]
+    for t, n in ((rz, "rz"), (alpha_out, "alpha_out"), (init_norm, "init_norm")):
+        _dev(t, n, torch.float64, 1)
+    if err_out.dtype != torch.float64 or err_out.numel() != k or not err_out.is_contiguous():
+        raise TypeError("err_out: expected float64 [k], contiguous")
+    return _lib.check(_LIB.xgpr_cg_step1_block_f64(
+        *ptrs, C.c_void_p(rz.data_ptr()), C.c_void_p(alpha_out.data_ptr()), C.c_void_p(err_out.data_ptr()),
+        C.c_void_p(init_norm.data_ptr()), float(lam2), m, k, C.c_void_p(workspace.data_ptr()),
+        C.c_size_t(workspace.numel()), _stream()))
+
+
+def hipCGStep2Block(r_next, z_next, p, p_next, rz, beta_out, workspace):
+    """cg_tools.py:271-274 for a block of right-hand sides."""
+    m, k = r_next.shape
+    ptrs = [_blk(t, n, k) for t, n in ((r_next, "r_next"), (z_next, "z_next"), (p, "p"), (p_next, "p_next"))]
+    _dev(rz, "rz", torch.float64, 1)
+    _dev(beta_out, "beta_out", torch.float64, 1)
+    return _lib.check(_LIB.xgpr_cg_step2_block_f64(*ptrs, C.c_void_p(rz.data_ptr()), C.c_void_p(beta_out.data_ptr()),
+                                                   m, k, C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()),
+                                                   _stream()))
+
+
+PRECOND_UTR_BLOCK_MAX_K = 32
+
+
+def precond_utr_block_workspace_bytes(m, rank, k):
+    return int(_LIB.xgpr_precond_utr_block_workspace_bytes(m, rank, k))
+
+
+def hipPrecondUtRBlock(u_mat, rmat, tout, workspace=None):
+    """``tout[rank, k] = u_mat.T @ rmat`` for a block of k <= 32 right-hand sides (the first product of
+    rand_nys_preconditioners.py:66-72; the library's skinny GEMM takes 15x as long at rank 512, k = 26)."""
+    _dev(u_mat, "u_mat", torch.float64, 2)
+    _dev(rmat, "rmat", torch.float64, 2)
+    _dev(tout, "tout", torch.float64, 2)
+    m, rank = u_mat.shape
+    k = rmat.shape[1]
+    if rmat.shape[0] != m or tuple(tout.shape) != (rank, k):
+        raise TypeError("hipPrecondUtRBlock: expected rmat [M, k] and tout [rank, k]")
+    if workspace is None:
+        workspace = torch.empty(precond_utr_block_workspace_bytes(m, rank, k), dtype=torch.uint8, device=u_mat.device)
+    return _lib.check(_LIB.xgpr_precond_utr_block_f64(
+        C.c_void_p(u_mat.data_ptr()), C.c_void_p(rmat.data_ptr()), C.c_void_p(tout.data_ptr()), m, rank, k,
+        C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
+
+
 def hipPrecondApply(u_mat, inv_eig, prefactor, rvec, zvec, workspace=None):
     """RandNysPreconditioner.batch_matvec for one right-hand side
     (preconditioners/rand_nys_preconditioners.py:66-72): zvec <- P^-1 rvec."""
