@@ -240,11 +240,16 @@ int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *
 }
 
 namespace {
-constexpr long UTRB_MAX_BLOCKS = 128;
-long utrb_blocks(long M) { const long b = (M + 63) / 64; return b < UTRB_MAX_BLOCKS ? (b > 0 ? b : 1) : UTRB_MAX_BLOCKS; }
+constexpr long UTRB_MAX_BLOCKS = 128;      // (workspace sized for up to 512 blocks: XGPR_UTRB_BLOCKS)
+long utrb_blocks(long M) {
+    static const long forced = [] { const char *e = getenv("XGPR_UTRB_BLOCKS"); return e ? atol(e) : 0L; }();   // timing experiments
+    const long cap = forced > 0 ? forced : UTRB_MAX_BLOCKS;
+    const long b = (M + 63) / 64;
+    return b < cap ? (b > 0 ? b : 1) : cap;
+}
 }  // namespace
 size_t xgpr_precond_utr_block_workspace_bytes(long M, long rank, long k) {
-    return (size_t)utrb_blocks(M) * (size_t)rank * (size_t)k * sizeof(double);
+    return (size_t)(utrb_blocks(M) > 512 ? utrb_blocks(M) : 512) * (size_t)rank * (size_t)k * sizeof(double);
 }
 int xgpr_precond_utr_block_f64(const double *u, const double *r, double *t_out, long M, long rank, long k,
                                void *workspace, size_t workspace_bytes, void *stream) {
