@@ -260,7 +260,7 @@ class ConjugateGrad:
         cws = torch.empty(ext.cg_block_workspace_bytes(m, k), dtype=torch.uint8, device=dev)
         if preconditioner is not None:
             u_mat = preconditioner.u_mat
-            u_scaled = u_mat * (preconditioner.inv_eig * preconditioner.prefactor - 1.0)[None, :]
+            coef = (preconditioner.inv_eig * preconditioner.prefactor - 1.0)[:, None].contiguous()
             u_t = u_mat.T
             utr = torch.empty((u_mat.shape[1], k), **f64)
             own_utr = k <= ext.PRECOND_UTR_BLOCK_MAX_K
@@ -275,7 +275,8 @@ class ConjugateGrad:
                     ext.hipPrecondUtRBlock(u_mat, src, utr, uws)
                 else:
                     torch.mm(u_t, src, out=utr)
-                torch.addmm(src, u_scaled, utr, out=dst)
+                utr.mul_(coef)
+                torch.addmm(src, u_mat, utr, out=dst)
 
         precond(r[0], z[0])
         p[0].copy_(z[0])
