@@ -340,6 +340,54 @@ def config_share(which, device, rows=None):
     return out
 
 
+def nmll_probe(device, rows=262144):
+    """The approximate NMLL (one preconditioned CG solve with k = 26 right-hand sides + stochastic Lanczos
+    quadrature, xgp_regression.py:264-367) at cfg3's shape on a 262 144-row shard with resident float32 features: what an
+    iteration of the batched solve costs beside its block matvec."""
+    import numpy as np
+    import torch
+    from xgpr_amd.kernels import make_kernel, block_workspace_bytes
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.nmll import approximate_nmll
+    d, m, k = 1024, 8192, 26
+    g = torch.Generator(device=device).manual_seed(123)
+    x = torch.randn(rows, d, device=device, generator=g) / d ** 0.5
+    a = torch.randn(d, device=device, generator=g)
+    y = (torch.sin(x @ a) + 0.1 * torch.randn(rows, device=device, generator=g)).double()
+    ds = build_regression_dataset(x, y, chunk_size=16384, device=device)
+    kern = make_kernel("Matern", (rows, d), m, 123, device, {"matern_nu": 2.5})
+    kern.set_hyperparams(np.array([0.3, 1.0]), logspace=False)
+    pre = RandNysPreconditioner(kern, ds, 512, False, 123, "srht")
+    zc = ds.feature_cache(kern)
+    det = {}
+    approximate_nmll(kern, ds, pre, None, 123, True, det)                  # first launches, untimed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    val = approximate_nmll(kern, ds, pre, None, 123, True, det)
+    torch.cuda.synchronize()
+    t_nmll = time.perf_counter() - t0
+    vb = torch.randn((m, k), dtype=torch.float64, device=device, generator=g)
+    wb = torch.empty_like(vb)
+    bws = torch.empty(block_workspace_bytes(rows, m, k), dtype=torch.uint8, device=device)
+    kern.ztz_block_cached(zc, vb, wb, bws)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        kern.ztz_block_cached(zc, vb, wb, bws)
+    e1.record()
+    e1.synchronize()
+    mv_ms = e0.elapsed_time(e1) / 5
+    out = {"workload": "approximate NMLL, Matern-5/2, %d rows x d=1024, 8192 RFFs, 26 right-hand sides, rank-512 preconditioner, "
+                       "resident float32 features" % rows,
+           "iterations": int(det["niter"]), "seconds": t_nmll, "ms_per_iteration": 1e3 * t_nmll / det["niter"],
+           "block_matvec_ms": mv_ms, "nmll": val}
+    ds._zcache = None
+    del zc, ds, pre, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
 def valu_only_probe(kern, ds, kern_ms, device):
     """Times the fused matvec of this rank's shard through the VALU-only timing probe (tools/, xgpr_amd/build.py PROBE_LIB: the
     kernel's vector instruction stream with LDS traffic, barrier and prefetch compiled out; results meaningless, never
@@ -677,6 +725,7 @@ def main():
         del pre, ds_pre, ds, x, y, cg
         torch.cuda.empty_cache()
         configs = {c: config_share(c, device) for c in ("cfg2", "cfg4", "cfg5")}
+        configs["nmll_k26"] = nmll_probe(device)
 
     if comm.rank == 0:
         n_local = hi - lo
