@@ -210,6 +210,12 @@ int xgpr_cg_step1_block_f64(double *w, const double *p, double *x, const double 
 int xgpr_cg_step2_block_f64(const double *r_next, const double *z_next, const double *p, double *p_next, const double *rz,
                             double *beta_out, long M, long k, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The classifier's cost function between its projection and back-projection
+ * (src/xGPR/fitting_toolkit/nonlinear_cg_toolkit.py:243-262): pred [n, ncls] float64 row-major is replaced, row by row,
+ * by softmax_2.71828(pred) - onehot(label); loss_partials [ceil(n / 256)] receives per-workgroup sums of
+ * -log(max(p[label], 1e-16)) (the caller adds them); labels int64 [n] in [0, ncls). */
+int xgpr_softmax_residual_f64(double *pred, const long *labels, long n, long ncls, double *loss_partials, void *stream);
+
 /* The first product of RandNysPreconditioner.batch_matvec for a block of right-hand sides
  * (src/xGPR/preconditioners/rand_nys_preconditioners.py:68, `self.u_mat.T @ xvec`): t_out [rank, k] = U^T R with
  * U [M, rank], R [M, k] float64 row-major, k <= 32; per-row-block partial sums in the workspace, added in block order. */

@@ -130,3 +130,29 @@ def test_classifier_cost_with_more_than_32_classes(oracle):
     probs = predict_proba(kern, torch.from_numpy(w0).to(DEV), torch.zeros(ncls, dtype=torch.float64, device=DEV),
                           torch.from_numpy(x[:50]).to(DEV))
     assert np.allclose(probs.cpu().numpy(), orc.predict_proba(okern, w0, x[:50].astype(np.float64)), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,ncls", [(1000, 3), (257, 10), (1, 2), (4099, 40)])
+def test_softmax_residual_kernel_equals_the_reference_chain(n, ncls):
+    """hipSoftmaxResidual (one launch) against the chain of array operations of nonlinear_cg_toolkit.py:243-262: row
+    maximum, 2.71828 ** (.), normalisation, clipped log loss, residual; incl. rows whose label probability underflows
+    the 1e-16 clip."""
+    import torch
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    g = torch.Generator(device=DEV).manual_seed(n + ncls)
+    pred = torch.randn(n, ncls, dtype=torch.float64, device=DEV, generator=g) * 8.0
+    labels = torch.randint(0, ncls, (n,), device=DEV, generator=g)
+    pred[0, :] = 0.0
+    pred[0, (int(labels[0]) + 1) % ncls] = 80.0          # the label's probability is ~ e^-80: clipped at 1e-16
+    ref = pred.clone()
+    ref -= ref.max(dim=1, keepdim=True).values
+    ref = 2.71828 ** ref
+    ref /= ref.sum(dim=1, keepdim=True)
+    loss_ref = -torch.log(ref.clamp(min=1e-16)).gather(1, labels[:, None]).sum()
+    ref.scatter_add_(1, labels[:, None], torch.full((n, 1), -1.0, dtype=torch.float64, device=DEV))
+    out = pred.clone()
+    loss = ext.hipSoftmaxResidual(out, labels)
+    assert float((out - ref).abs().max()) < 1e-14
+    assert abs(float(loss) - float(loss_ref)) <= 1e-12 * abs(float(loss_ref))
+    out2 = pred.clone()
+    assert torch.equal(ext.hipSoftmaxResidual(out2, labels), loss) and torch.equal(out2, out)      # reproducible

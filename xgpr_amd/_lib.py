@@ -39,6 +39,7 @@ SIGNATURES = {
     "xgpr_zty_f32": [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_cg_step1_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _l, _d, _vp, _vp],
     "xgpr_cg_step2_f64": [_vp, _vp, _vp, _vp, _vp, _l, _d, _vp],
+    "xgpr_softmax_residual_f64": [_vp, _vp, _l, _l, _vp, _vp],
     "xgpr_precond_utr_block_f64": [_vp, _vp, _vp, _l, _l, _l, _vp, _sz, _vp],
     "xgpr_cg_step1_block_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _l, _l, _vp, _sz, _vp],
     "xgpr_cg_step2_block_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _vp, _sz, _vp],

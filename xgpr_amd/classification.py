@@ -122,13 +122,8 @@ class NonlinearCGClassification:
                     part = torch.empty((n, j1 - j0), dtype=torch.float64, device=dev)
                     ext.hipZCacheBlockProject(zc, wvec[:, j0:j1].contiguous(), part, icpt, scale)
                     pred[:, j0:j1] = part
-            pred -= pred.max(dim=1, keepdim=True).values
-            pred = 2.71828 ** pred                            # the reference's constant, not e
-            pred /= pred.sum(dim=1, keepdim=True)
-            idx = labels.to(torch.int64)
-            logpred = torch.log(pred.clamp(min=1e-16))
-            loss -= logpred.gather(1, idx[:, None]).sum()
-            pred.scatter_add_(1, idx[:, None], torch.full((n, 1), -1.0, dtype=torch.float64, device=dev))
+            # row maximum, 2.71828 ** (.) (the reference's constant, not e), normalisation, loss and residual: one launch
+            loss += ext.hipSoftmaxResidual(pred, labels.to(torch.int64).contiguous())
             for j0 in range(0, ncls, 32):
                 j1 = min(ncls, j0 + 32)
                 if j0 == 0 and j1 == ncls:

@@ -308,6 +308,16 @@ int xgpr_cg_step2_block_f64(const double *r_next, const double *z_next, const do
     return 0;
 }
 
+int xgpr_softmax_residual_f64(double *pred, const long *labels, long n, long ncls, double *loss_partials, void *stream) {
+    if (n <= 0 || ncls <= 0 || ncls > 2147483647L) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    const long nblk = (n + 255) / 256;
+    if (nblk > 2147483647L) return fail(XGPR_ERR_UNSUPPORTED, "too many datapoints for one launch");
+    hipLaunchKernelGGL(softmax_residual_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pred, labels, n, (int)ncls,
+                       loss_partials);
+    HIP_TRY(hipGetLastError(), "softmax_residual_kernel launch");
+    return 0;
+}
+
 size_t xgpr_precond_apply_workspace_bytes(long rank) { return (size_t)(PRE_BLOCKS + 1) * rank * sizeof(double); }
 int xgpr_precond_apply_f64(const double *u, const double *inv_eig, double prefactor, const double *r, double *z,
                            long M, long rank, void *workspace, size_t workspace_bytes, void *stream) {

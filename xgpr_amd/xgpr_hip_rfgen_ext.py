@@ -462,6 +462,21 @@ def _blk(t, name, k=None):
     return C.c_void_p(t.data_ptr())
 
 
+def hipSoftmaxResidual(pred, labels):
+    """nonlinear_cg_toolkit.py:243-262 on the device in one launch: ``pred`` [n, classes] float64 becomes
+    softmax_2.71828(pred) - onehot(labels) in place; returns the loss contribution -sum log(max(p[label], 1e-16))
+    as a one-element device tensor."""
+    _dev(pred, "pred", torch.float64, 2)
+    _dev(labels, "labels", torch.int64, 1)
+    n, ncls = pred.shape
+    if labels.shape[0] != n:
+        raise TypeError("labels: expected [n]")
+    parts = torch.empty((n + 255) // 256, dtype=torch.float64, device=pred.device)
+    _lib.check(_LIB.xgpr_softmax_residual_f64(C.c_void_p(pred.data_ptr()), C.c_void_p(labels.data_ptr()), n, ncls,
+                                              C.c_void_p(parts.data_ptr()), _stream()))
+    return parts.sum().reshape(1)
+
+
 CG_BLOCK_MAX_K = 32
 
 
