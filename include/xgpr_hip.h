@@ -223,6 +223,13 @@ size_t xgpr_precond_utr_block_workspace_bytes(long M, long rank, long k);
 int xgpr_precond_utr_block_f64(const double *u, const double *r, double *t_out, long M, long rank, long k,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* RandNysPreconditioner.batch_matvec for a block of k <= 32 right-hand sides, both products on the float64 matrix cores:
+ * z [M, k] = r + U ((inv_eig * prefactor - 1) .* (U^T r)) -- the reference's xprod2 + xprod1
+ * (src/xGPR/preconditioners/rand_nys_preconditioners.py:66-72) as two products; r, z [M, k] row-major, z != r. */
+size_t xgpr_precond_apply_block_workspace_bytes(long M, long rank, long k);
+int xgpr_precond_apply_block_f64(const double *u, const double *inv_eig, double prefactor, const double *r, double *z,
+                                 long M, long rank, long k, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- RandNysPreconditioner.batch_matvec for one right-hand side
  * (src/xGPR/preconditioners/rand_nys_preconditioners.py:66-72):
  *   z = U (inv_eig * prefactor .* U^T r) + (r - U U^T r),   U [M, rank] float64 row-major. */

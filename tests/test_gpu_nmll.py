@@ -283,3 +283,24 @@ def test_utr_block_kernel_equals_the_product(m, rank, k):
     assert torch.equal(t, t2)                           # fixed summation order
     with pytest.raises(RuntimeError):
         ext.hipPrecondUtRBlock(u, torch.zeros(m, 33, dtype=torch.float64, device=DEV), torch.zeros(rank, 33, dtype=torch.float64, device=DEV))
+
+
+@pytest.mark.parametrize("m,rank,k", [(8192, 512, 26), (2100, 48, 3), (1000, 513, 32), (70, 7, 1), (12288, 1030, 9), (4097, 130, 16)])
+def test_block_preconditioner_apply_equals_the_reference_form(m, rank, k):
+    """hipPrecondApplyBlock (both products on the float64 matrix cores) against batch_matvec as the reference writes it
+    (rand_nys_preconditioners.py:66-72: xprod2 + xprod1, three float64 products); ranks that are not multiples of 4 or
+    16, row counts that are not multiples of 16, one to thirty-two right-hand sides."""
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    g = torch.Generator(device=DEV).manual_seed(m + rank + k)
+    u = torch.linalg.qr(torch.randn(m, rank, dtype=torch.float64, device=DEV, generator=g))[0].contiguous()
+    inv_eig = 1.0 / (torch.rand(rank, dtype=torch.float64, device=DEV, generator=g) * 50 + 0.1)
+    pref = 0.37
+    r = torch.randn(m, k, dtype=torch.float64, device=DEV, generator=g)
+    z = torch.full((m, k), float("nan"), dtype=torch.float64, device=DEV)
+    ext.hipPrecondApplyBlock(u, inv_eig, pref, r, z)
+    xprod = u.T @ r
+    ref = (r - u @ xprod) + u @ (inv_eig[:, None] * pref * xprod)
+    assert float((z - ref).abs().max()) <= 1e-12 * float(ref.abs().max()) * np.sqrt(m)
+    z2 = torch.empty_like(z)
+    ext.hipPrecondApplyBlock(u, inv_eig, pref, r, z2)
+    assert torch.equal(z, z2)

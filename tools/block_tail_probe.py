@@ -37,9 +37,12 @@ res = {
 }
 uws = torch.empty(ext.precond_utr_block_workspace_bytes(m, rank, k), dtype=torch.uint8, device=dev)
 res["hipPrecondUtRBlock (2 launches)"] = timed(lambda i: ext.hipPrecondUtRBlock(u, rn, utr, uws))
+inv_eig = torch.rand(rank, generator=g, **f64) + 0.5
+pws = torch.empty(ext.precond_apply_block_workspace_bytes(m, rank, k), dtype=torch.uint8, device=dev)
+res["hipPrecondApplyBlock (3 launches)"] = timed(lambda i: ext.hipPrecondApplyBlock(u, inv_eig, 1.5, rn, zn, pws))
 def chain(i):
     ext.hipCGStep1Block(w, p, x, r, rn, z, rz, al, err[i], nrm, 0.01, cws)
-    ext.hipPrecondUtRBlock(u, rn, utr, uws); torch.addmm(rn, us, utr, out=zn)
+    ext.hipPrecondApplyBlock(u, inv_eig, 1.5, rn, zn, pws)
     ext.hipCGStep2Block(rn, zn, p, pn, rz, be, cws)
 res["chain"] = timed(chain)
 for kk, v in res.items(): print(f"{kk:22s} {v:8.2f} us")

@@ -41,6 +41,7 @@ SIGNATURES = {
     "xgpr_cg_step2_f64": [_vp, _vp, _vp, _vp, _vp, _l, _d, _vp],
     "xgpr_softmax_residual_f64": [_vp, _vp, _l, _l, _vp, _vp],
     "xgpr_precond_utr_block_f64": [_vp, _vp, _vp, _l, _l, _l, _vp, _sz, _vp],
+    "xgpr_precond_apply_block_f64": [_vp, _vp, _d, _vp, _vp, _l, _l, _l, _vp, _sz, _vp],
     "xgpr_cg_step1_block_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _l, _l, _vp, _sz, _vp],
     "xgpr_cg_step2_block_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _vp, _sz, _vp],
     "xgpr_precond_apply_f64": [_vp, _vp, _d, _vp, _vp, _l, _l, _vp, _sz, _vp],
@@ -66,6 +67,7 @@ SIZE_FUNCS = {
     "xgpr_conv_workspace_bytes": [_l, _l, _i, _l],
     "xgpr_precond_apply_workspace_bytes": [_l],
     "xgpr_precond_utr_block_workspace_bytes": [_l, _l, _l],
+    "xgpr_precond_apply_block_workspace_bytes": [_l, _l, _l],
     "xgpr_cg_block_workspace_bytes": [_l, _l],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
     "xgpr_zcache_block_workspace_bytes": [_l, _l, _l],

@@ -259,24 +259,14 @@ class ConjugateGrad:
         lam2 = float(kernel.get_lambda()) ** 2
         cws = torch.empty(ext.cg_block_workspace_bytes(m, k), dtype=torch.uint8, device=dev)
         if preconditioner is not None:
-            u_mat = preconditioner.u_mat
-            coef = (preconditioner.inv_eig * preconditioner.prefactor - 1.0)[:, None].contiguous()
-            u_t = u_mat.T
-            utr = torch.empty((u_mat.shape[1], k), **f64)
-            own_utr = k <= ext.PRECOND_UTR_BLOCK_MAX_K
-            if own_utr:
-                uws = torch.empty(ext.precond_utr_block_workspace_bytes(m, u_mat.shape[1], k), dtype=torch.uint8, device=dev)
+            u_mat, inv_eig, pref = preconditioner.u_mat, preconditioner.inv_eig, preconditioner.prefactor
+            pws = torch.empty(ext.precond_apply_block_workspace_bytes(m, u_mat.shape[1], k), dtype=torch.uint8, device=dev)
 
         def precond(src, dst):
             if preconditioner is None:
                 dst.copy_(src)
             else:
-                if own_utr:
-                    ext.hipPrecondUtRBlock(u_mat, src, utr, uws)
-                else:
-                    torch.mm(u_t, src, out=utr)
-                utr.mul_(coef)
-                torch.addmm(src, u_mat, utr, out=dst)
+                ext.hipPrecondApplyBlock(u_mat, inv_eig, pref, src, dst, pws)
 
         precond(r[0], z[0])
         p[0].copy_(z[0])

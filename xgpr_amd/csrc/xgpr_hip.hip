@@ -240,35 +240,56 @@ int xgpr_cg_step2_f64(const double *r_next, const double *z_next, const double *
 }
 
 namespace {
-constexpr long UTRB_MAX_BLOCKS = 128;      // (workspace sized for up to 512 blocks: XGPR_UTRB_BLOCKS)
-long utrb_blocks(long M) {
-    static const long forced = [] { const char *e = getenv("XGPR_UTRB_BLOCKS"); return e ? atol(e) : 0L; }();   // timing experiments
-    const long cap = forced > 0 ? forced : UTRB_MAX_BLOCKS;
-    const long b = (M + 63) / 64;
-    return b < cap ? (b > 0 ? b : 1) : cap;
+constexpr long UTRB_MAX_BLOCKS = 64;
+struct UtrbGeom { long nrb; long rows_per; };
+UtrbGeom utrb_geometry(long M) {
+    long nrb = (M + 63) / 64;
+    if (nrb > UTRB_MAX_BLOCKS) nrb = UTRB_MAX_BLOCKS;
+    if (nrb < 1) nrb = 1;
+    const long rows_per = ((M + nrb - 1) / nrb + 3) / 4 * 4;
+    return {(M + rows_per - 1) / rows_per, rows_per};
+}
+int utr_block_launch(const double *u, const double *r, double *t_out, long M, long rank, long k, double *part, hipStream_t st) {
+    const UtrbGeom gm = utrb_geometry(M);
+    const dim3 grid((unsigned)((rank + 127) / 128), (unsigned)gm.nrb);
+    if (k <= 16) hipLaunchKernelGGL((precond_utr_mfma_kernel<1>), grid, dim3(512), 0, st, u, r, part, M, rank, (int)k, gm.rows_per);
+    else hipLaunchKernelGGL((precond_utr_mfma_kernel<2>), grid, dim3(512), 0, st, u, r, part, M, rank, (int)k, gm.rows_per);
+    HIP_TRY(hipGetLastError(), "precond_utr_mfma_kernel launch");
+    const long total = rank * k;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, t_out, total, gm.nrb);
+    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    return 0;
 }
 }  // namespace
 size_t xgpr_precond_utr_block_workspace_bytes(long M, long rank, long k) {
-    return (size_t)(utrb_blocks(M) > 512 ? utrb_blocks(M) : 512) * (size_t)rank * (size_t)k * sizeof(double);
+    return (size_t)utrb_geometry(M).nrb * (size_t)rank * (size_t)k * sizeof(double);
 }
 int xgpr_precond_utr_block_f64(const double *u, const double *r, double *t_out, long M, long rank, long k,
                                void *workspace, size_t workspace_bytes, void *stream) {
     if (M <= 0 || rank <= 0 || k <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
-    if (k > UTRB_KMAX) return fail(XGPR_ERR_UNSUPPORTED, "U^T R block kernel takes at most 32 right-hand sides");
+    if (k > 32) return fail(XGPR_ERR_UNSUPPORTED, "U^T R block kernel takes at most 32 right-hand sides");
     if (!workspace || workspace_bytes < xgpr_precond_utr_block_workspace_bytes(M, rank, k) || !aligned16(workspace))
         return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_precond_utr_block_workspace_bytes)");
+    return utr_block_launch(u, r, t_out, M, rank, k, reinterpret_cast<double *>(workspace), (hipStream_t)stream);
+}
+size_t xgpr_precond_apply_block_workspace_bytes(long M, long rank, long k) {
+    return xgpr_precond_utr_block_workspace_bytes(M, rank, k) + (size_t)rank * (size_t)k * sizeof(double);
+}
+int xgpr_precond_apply_block_f64(const double *u, const double *inv_eig, double prefactor, const double *r, double *z,
+                                 long M, long rank, long k, void *workspace, size_t workspace_bytes, void *stream) {
+    if (M <= 0 || rank <= 0 || k <= 0) return fail(XGPR_ERR_ARRAY_DIMS, "incorrect array dims passed");
+    if (k > 32) return fail(XGPR_ERR_UNSUPPORTED, "block preconditioner apply takes at most 32 right-hand sides");
+    if (!workspace || workspace_bytes < xgpr_precond_apply_block_workspace_bytes(M, rank, k) || !aligned16(workspace))
+        return fail(XGPR_ERR_WORKSPACE, "workspace too small (see xgpr_precond_apply_block_workspace_bytes)");
     hipStream_t st = (hipStream_t)stream;
-    const long nb = utrb_blocks(M);
-    const long rows_per = (M + nb - 1) / nb;
     double *part = reinterpret_cast<double *>(workspace);
-#define UTRB_LAUNCH(KP) hipLaunchKernelGGL((precond_utr_block_kernel<KP>), dim3((unsigned)nb), dim3(256), 0, st, u, r, part, M, rank, (int)k, rows_per)
-    if (k <= 4) UTRB_LAUNCH(4); else if (k <= 8) UTRB_LAUNCH(8); else if (k <= 16) UTRB_LAUNCH(16);
-    else if (k <= 28) UTRB_LAUNCH(28); else UTRB_LAUNCH(32);
-#undef UTRB_LAUNCH
-    HIP_TRY(hipGetLastError(), "precond_utr_block_kernel launch");
-    const long total = rank * k;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, part, t_out, total, nb);
-    HIP_TRY(hipGetLastError(), "reduce_slabs_kernel launch");
+    double *t = part + (size_t)utrb_geometry(M).nrb * rank * k;
+    int rc = utr_block_launch(u, r, t, M, rank, k, part, st);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((M + 15) / 16));
+    if (k <= 16) hipLaunchKernelGGL((precond_uz_mfma_kernel<1>), grid, dim3(256), 0, st, u, t, inv_eig, prefactor, r, z, M, rank, (int)k);
+    else hipLaunchKernelGGL((precond_uz_mfma_kernel<2>), grid, dim3(256), 0, st, u, t, inv_eig, prefactor, r, z, M, rank, (int)k);
+    HIP_TRY(hipGetLastError(), "precond_uz_mfma_kernel launch");
     return 0;
 }
 

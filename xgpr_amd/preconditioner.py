@@ -427,16 +427,14 @@ class RandNysPreconditioner:
 
     def batch_matvec(self, xvec):
         """rand_nys_preconditioners.py:66-72.  Blocks of up to 32 float64 right-hand sides on the device take
-        x + U ((inv_eig * prefactor - 1) .* (U^T x)) -- the same operator in two products -- with U^T x from
-        hipPrecondUtRBlock (the library's skinny GEMM for that shape takes 220 us at rank 512, three times the rest of
-        the apply)."""
+        x + U ((inv_eig * prefactor - 1) .* (U^T x)) -- the same operator in two products -- through
+        hipPrecondApplyBlock (float64 matrix cores; the library's skinny GEMM for U^T x takes 220 us at rank 512)."""
         if (xvec.is_cuda and xvec.dim() == 2 and xvec.dtype == torch.float64
                 and 1 <= xvec.shape[1] <= ext.PRECOND_UTR_BLOCK_MAX_K and xvec.shape[0] == self.u_mat.shape[0]):
             xc = xvec.contiguous()
-            utx = torch.empty((self.u_mat.shape[1], xc.shape[1]), dtype=torch.float64, device=xc.device)
-            ext.hipPrecondUtRBlock(self.u_mat, xc, utx)
-            utx *= (self.inv_eig * self.prefactor - 1.0)[:, None]
-            return torch.addmm(xc, self.u_mat, utx)
+            out = torch.empty_like(xc)
+            ext.hipPrecondApplyBlock(self.u_mat, self.inv_eig, self.prefactor, xc, out)
+            return out
         xprod = self.u_mat.T @ xvec
         xprod1 = self.u_mat @ (self.inv_eig[:, None] * self.prefactor * xprod)
         xprod2 = xvec - (self.u_mat @ xprod)

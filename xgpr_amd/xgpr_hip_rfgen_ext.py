@@ -534,6 +534,28 @@ def hipPrecondUtRBlock(u_mat, rmat, tout, workspace=None):
         C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
 
 
+def precond_apply_block_workspace_bytes(m, rank, k):
+    return int(_LIB.xgpr_precond_apply_block_workspace_bytes(m, rank, k))
+
+
+def hipPrecondApplyBlock(u_mat, inv_eig, prefactor, rmat, zmat, workspace=None):
+    """RandNysPreconditioner.batch_matvec for a block of k <= 32 right-hand sides (rand_nys_preconditioners.py:66-72):
+    ``zmat <- rmat + U ((inv_eig * prefactor - 1) .* (U^T rmat))``, both products on the float64 matrix cores."""
+    _dev(u_mat, "u_mat", torch.float64, 2)
+    _dev(inv_eig, "inv_eig", torch.float64, 1)
+    _dev(rmat, "rmat", torch.float64, 2)
+    _dev(zmat, "zmat", torch.float64, 2)
+    m, rank = u_mat.shape
+    k = rmat.shape[1]
+    if rmat.shape[0] != m or tuple(zmat.shape) != (m, k) or inv_eig.shape[0] != rank or zmat.data_ptr() == rmat.data_ptr():
+        raise TypeError("hipPrecondApplyBlock: expected rmat, zmat [M, k] (distinct) and inv_eig [rank]")
+    if workspace is None:
+        workspace = torch.empty(precond_apply_block_workspace_bytes(m, rank, k), dtype=torch.uint8, device=u_mat.device)
+    return _lib.check(_LIB.xgpr_precond_apply_block_f64(
+        C.c_void_p(u_mat.data_ptr()), C.c_void_p(inv_eig.data_ptr()), float(prefactor), C.c_void_p(rmat.data_ptr()),
+        C.c_void_p(zmat.data_ptr()), m, rank, k, C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
+
+
 def hipPrecondApply(u_mat, inv_eig, prefactor, rvec, zvec, workspace=None):
     """RandNysPreconditioner.batch_matvec for one right-hand side
     (preconditioners/rand_nys_preconditioners.py:66-72): zvec <- P^-1 rvec."""
