@@ -246,3 +246,51 @@ def test_two_pass_matvec_across_row_windows_is_additive():
     k.ztz_matvec(x[:131_072], v, a, ws)
     k.ztz_matvec(x[131_072:], v, b, ws)
     assert float((full - (a + b)).abs().max() / full.abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("cfg,rows", [("cfg2", 200_000), ("cfg3", 131_072)])
+def test_feature_operator_under_load_matches_the_oracle_on_sampled_rows(oracle, cfg, rows):
+    """Datapoints are independent, so a launch over 10^5 rows (every CU busy, loads and stores in flight everywhere)
+    can be checked against the CPU oracle on a random sample of its rows: the float64 operator (wave_rbf_kernel) and the
+    float32 cache rows (ztz3_kernel Z3_FEAT32).  Properties like unit norm cannot see a row computed from stale data;
+    this can."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    d, m = (256, 4096) if cfg == "cfg2" else (1024, 8192)
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    x = torch.randn(rows, d, device=DEV, generator=g) / d ** 0.5
+    radem, chi = orc.draw_sorf_params(m, d, 123)
+    rt, ct = torch.from_numpy(radem).to(DEV), torch.from_numpy(chi).to(DEV)
+    z = torch.zeros((rows, m), dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(x, z, rt, ct, True)
+    zc = torch.empty((rows, m), dtype=torch.float32, device=DEV)
+    ext.hipRBFFeatureCache(x, zc, rt, ct)
+    pick = torch.from_numpy(np.random.default_rng(5).choice(rows, 384, replace=False)).to(DEV)
+    xs = x[pick].cpu().numpy()
+    ref = np.zeros((xs.shape[0], m))
+    oracle.cpuRBFFeatureGen(xs.copy(), ref, radem, chi, True)
+    scale = np.sqrt(1.0 / (m // 2 - 0.5))
+    assert np.abs(z[pick].cpu().numpy() - ref).max() <= 4e-7 * scale
+    assert np.abs(zc[pick].double().cpu().numpy() * float(np.float32(scale)) - ref).max() <= 4e-7 * scale
+    del z, zc
+
+
+def test_convolution_operator_under_load_matches_the_oracle_on_sampled_sequences(oracle):
+    """The same for the convolution feature operator at cfg4's shape (L <= 512, 21 channels, conv_width 9, 16384 RFFs):
+    8192 sequences in one launch, 48 of them against the oracle."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    nseq, L, C, m, w = 8192, 512, 21, 16384, 9
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.nn.functional.one_hot(torch.randint(0, C, (nseq, L), device=DEV, generator=g), C).to(torch.float32)
+    sl = np.random.default_rng(5).integers(64, L + 1, size=nseq).astype(np.int32)
+    radem, chi = orc.draw_sorf_params(m, w * C, 123, conv=True)
+    out = torch.zeros((nseq, m), dtype=torch.float64, device=DEV)
+    ext.hipConv1dFGen(x, out, torch.from_numpy(radem).to(DEV), torch.from_numpy(chi).to(DEV), sl, w, 1)
+    pick = np.sort(np.random.default_rng(6).choice(nseq, 48, replace=False))
+    xs = x[torch.from_numpy(pick).to(DEV)].cpu().numpy()
+    ref = np.zeros((len(pick), m))
+    oracle.cpuConv1dFGen(xs, ref, radem, chi, sl[pick], w, 1)
+    got = out[torch.from_numpy(pick).to(DEV)].cpu().numpy()
+    kmax = int(sl[pick].max()) - w + 1
+    assert np.abs(got - ref).max() <= 4e-7 * np.sqrt(2.0 / m) * np.sqrt(kmax)
