@@ -31,6 +31,8 @@ for case in range(cases):
     d = int(rng.choice([3, 20, 32, 100, 128, 256, 300, 512, 700, 1024]))
     rffs = int(rng.choice([64, 512, 2048, 3000, 4096, 6144, 8192, 12288, 16384])) // 2 * 2
     n = int(rng.integers(1, 700))
+    if case % 4 == 3 and rffs <= 4096:
+        n = int(rng.integers(20000, 60000))      # a launch that fills the chip: loads and stores in flight everywhere
     icpt = bool(rng.integers(0, 2))
     radem, chi = orc.draw_sorf_params(rffs, d, int(rng.integers(1, 1000)))
     x = (rng.standard_normal((n, d)) / np.sqrt(d) * rng.choice([1.0, 1.0, 30.0])).astype(np.float32)
@@ -74,6 +76,8 @@ for case in range(cases):
     C = int(rng.choice([4, 21, 64])); cw = int(rng.integers(1, 17)); L = cw + int(rng.integers(0, 40))
     m2 = int(rng.choice([64, 600, 1024, 2048]))
     ns = int(rng.integers(1, 9))
+    if case % 4 == 1:
+        ns = int(rng.integers(300, 900))          # many sequences in one launch (see tests/test_gpu_conv_long_windows.py)
     radem2, chi2 = orc.draw_sorf_params(m2, cw * C, 77, conv=True)
     xs = rng.standard_normal((ns, L, C)).astype(np.float32)
     sl = rng.integers(cw, L + 1, size=ns).astype(np.int32)
