@@ -294,3 +294,59 @@ def test_convolution_operator_under_load_matches_the_oracle_on_sampled_sequences
     got = out[torch.from_numpy(pick).to(DEV)].cpu().numpy()
     kmax = int(sl[pick].max()) - w + 1
     assert np.abs(got - ref).max() <= 4e-7 * np.sqrt(2.0 / m) * np.sqrt(kmax)
+
+
+def test_gradient_and_maxpool_operators_under_load_match_the_oracle_on_sampled_rows(oracle):
+    """cudaRBFGrad, cudaConvGrad and cudaConv1dMaxpool launched over enough rows / sequences to fill the chip, sampled
+    rows against the oracle (max-pool: bit for bit)."""
+    from scipy.stats import chi as chi_dist
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(11)
+    # --- cudaRBFGrad
+    n, d, m, sigma = 100_000, 256, 2048, 0.9
+    g = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.randn(n, d, device=DEV, generator=g) / d ** 0.5
+    radem, chi = orc.draw_sorf_params(m, d, 123)
+    out = torch.zeros((n, m), dtype=torch.float64, device=DEV)
+    grad = torch.zeros((n, m, 1), dtype=torch.float64, device=DEV)
+    ext.hipRBFGrad(x, out, grad, torch.from_numpy(radem).to(DEV), torch.from_numpy(chi).to(DEV), sigma, True)
+    pick = torch.from_numpy(rng.choice(n, 256, replace=False)).to(DEV)
+    xs = x[pick].cpu().numpy()
+    oref, gref = np.zeros((256, m)), np.zeros((256, m, 1))
+    oracle.cpuRBFGrad(xs.copy(), oref, gref, radem, chi, sigma, True)
+    scale = np.sqrt(1.0 / (m // 2 - 0.5))
+    assert np.abs(out[pick].cpu().numpy() - oref).max() <= 4e-7 * scale
+    assert np.abs(grad[pick].cpu().numpy() - gref).max() <= 4e-7 * scale * max(1.0, float(np.abs(gref).max() / scale))
+    del out, grad, x
+    # --- cudaConvGrad and cudaConv1dMaxpool
+    nseq, L, C, w = 4096, 160, 21, 9
+    xc = np.zeros((nseq, L, C), dtype=np.float32)
+    xc[np.arange(nseq)[:, None], np.arange(L)[None, :], rng.integers(0, C, (nseq, L))] = 1.0
+    xc += 0.01 * rng.standard_normal(xc.shape).astype(np.float32)
+    sl = rng.integers(w, L + 1, size=nseq).astype(np.int32)
+    xt = torch.from_numpy(xc).to(DEV)
+    sub = np.sort(rng.choice(nseq, 32, replace=False))
+    m2 = 2048
+    radem2, chi2 = orc.draw_sorf_params(m2, w * C, 77, conv=True)
+    o2 = torch.zeros((nseq, m2), dtype=torch.float64, device=DEV)
+    g2 = torch.zeros((nseq, m2, 1), dtype=torch.float64, device=DEV)
+    ext.hipConvGrad(xt, o2, torch.from_numpy(radem2).to(DEV), torch.from_numpy(chi2).to(DEV), sl, g2, 0.8, w, 1)
+    oref2, gref2 = np.zeros((32, m2)), np.zeros((32, m2, 1))
+    oracle.cpuConvGrad(xc[sub], oref2, radem2, chi2, sl[sub], gref2, 0.8, w, 1)
+    kmax = int(sl[sub].max()) - w + 1
+    bar = 4e-7 * np.sqrt(2.0 / m2) * np.sqrt(kmax)
+    subt = torch.from_numpy(sub).to(DEV)
+    assert np.abs(o2[subt].cpu().numpy() - oref2).max() <= bar
+    assert np.abs(g2[subt].cpu().numpy() - gref2).max() <= bar * max(1.0, float(np.abs(gref2).max() / np.abs(oref2).max()))
+    del o2, g2
+    mp = 1024                                                  # max-pool: num_freqs = num_rffs, radem length = reps x padded width
+    pw = 256
+    prng = np.random.default_rng(5)
+    radem3 = prng.choice(np.asarray([-1, 1], dtype=np.int8), size=(3, 1, mp), replace=True)
+    chi3 = chi_dist.rvs(df=pw, size=mp, random_state=5).astype(np.float32)
+    o3 = torch.zeros((nseq, mp), dtype=torch.float32, device=DEV)
+    ext.hipConv1dMaxpool(xt, o3, torch.from_numpy(radem3).to(DEV), torch.from_numpy(chi3).to(DEV), sl, w)
+    oref3 = np.zeros((32, mp), dtype=np.float32)
+    oracle.cpuConv1dMaxpool(xc[sub], oref3, radem3, chi3, sl[sub], w)
+    assert np.array_equal(o3[subt].cpu().numpy(), oref3)
