@@ -42,3 +42,18 @@ def refcore():
     if not orc.RefCore.available():
         pytest.skip("reference core not built (no /root/reference on this box)")
     return orc.RefCore()
+
+
+# Development aid: XGPR_POISON_EMPTY=1 fills every tensor that torch.empty hands out on the GPU with 0xFF bytes (NaN as
+# float32 / float64, -1 as integers) -- workspaces and output buffers alike -- so that a kernel that reads memory nobody
+# wrote, or leaves part of its output unwritten, turns a test red instead of passing on whatever the allocator returned.
+if os.environ.get("XGPR_POISON_EMPTY") == "1":
+    import torch as _torch
+    _orig_empty = _torch.empty
+
+    def _poisoned_empty(*args, **kwargs):
+        t = _orig_empty(*args, **kwargs)
+        if t.is_cuda and t.numel() > 0 and t.dtype in (_torch.uint8, _torch.float32, _torch.float64, _torch.int32, _torch.int64):
+            t.view(_torch.uint8).fill_(255) if t.is_contiguous() else None
+        return t
+    _torch.empty = _poisoned_empty
