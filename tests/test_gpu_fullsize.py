@@ -350,3 +350,25 @@ def test_gradient_and_maxpool_operators_under_load_match_the_oracle_on_sampled_r
     oref3 = np.zeros((32, mp), dtype=np.float32)
     oracle.cpuConv1dMaxpool(xc[sub], oref3, radem3, chi3, sl[sub], w)
     assert np.array_equal(o3[subt].cpu().numpy(), oref3)
+
+
+@pytest.mark.parametrize("n,d,m,dtype", [(30_000, 2000, 4096, np.float32), (30_000, 300, 2048, np.float64),
+                                         (1500, 20_000, 65_536, np.float64), (1500, 20_000, 65_536, np.float32)])
+def test_generic_width_paths_under_load_match_the_oracle_on_sampled_rows(oracle, n, d, m, dtype):
+    """The operators' general path (generic_sorf_kernel: padded widths above 1024, float64 inputs; butterflies in LDS,
+    and in a global scratch region per workgroup once a padded row no longer fits in LDS -- 32768 float64 = 256 KiB)
+    launched over enough rows to keep every CU's scratch region busy, sampled rows against the oracle."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    rng = np.random.default_rng(d + m)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(dtype)
+    radem, chi = orc.draw_sorf_params(m, d, 123, double_precision=(dtype == np.float64))
+    xt = torch.from_numpy(x).to(DEV)
+    out = torch.zeros((n, m), dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(xt, out, torch.from_numpy(radem).to(DEV), torch.from_numpy(chi).to(DEV), False)
+    pick = np.sort(rng.choice(n, 96, replace=False))
+    ref = np.zeros((96, m))
+    oracle.cpuRBFFeatureGen(x[pick].copy(), ref, radem, chi, False)
+    scale = np.sqrt(1.0 / (m // 2))
+    tol = 4e-7 if dtype == np.float32 else 1e-12
+    assert np.abs(out[torch.from_numpy(pick).to(DEV)].cpu().numpy() - ref).max() <= tol * scale * (1 if dtype == np.float32 else 1e3)
