@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("conv_width,nseq", [(24, 768), (48, 512), (13, 768)])
+@pytest.mark.parametrize("conv_width,nseq", [(24, 768), (48, 512), (13, 768), (64, 384)])   # (64 x 21 = 1344: the general path, padded width 2048)
 def test_long_window_features_match_the_oracle_under_load(oracle, conv_width, nseq):
     from oracle import oracle as orc
     from xgpr_amd import xgpr_hip_rfgen_ext as ext
