@@ -48,6 +48,9 @@ extern "C" {
 const char *xgpr_last_error(void);
 /* "gfx950" etc: the offload architecture the device code was built for. */
 const char *xgpr_build_arch(void);
+/* sha256 (hex) of the sources (xgpr_amd/csrc/ *, this header) and compiler flags the binary was built from, as
+ * xgpr_amd/build.py source_id() computes it; "unidentified" for a hand-compiled library */
+const char *xgpr_build_id(void);
 
 /* ---- bare FHT: cudaFastHadamardTransform2D (xgpr_cuda_rfgen_cpp_ext.cpp:21-24) and the
  * CPU-only 3-D form cpuFastHadamardTransform (xgpr_cpu_rfgen_cpp_ext.cpp:24-30).

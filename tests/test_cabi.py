@@ -34,6 +34,48 @@ def test_ctypes_table_matches_header():
     assert lib.xgpr_rbf_workspace_bytes(4096) >= 3 * 4096 // 8
 
 
+def _build_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("xgpr_amd_build_t", os.path.join(ROOT, "xgpr_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_library_identifies_its_sources():
+    """xgpr_build_id() == sha256 of csrc/*, include/xgpr_hip.h and the flag list of THIS tree (build.py source_id)."""
+    from xgpr_amd import _lib
+    bm = _build_module()
+    bm.build_extension()
+    assert bm.built_id(bm.LIB) == bm.source_id()
+    assert _lib.build_id() == bm.source_id() and len(_lib.build_id()) == 64
+
+
+def test_build_rebuilds_on_source_mismatch_not_on_mtime(tmp_path, monkeypatch):
+    """A library built from OTHER sources is rebuilt even when it is newer than every source file (a checkout of older
+    sources); one built from these sources is kept even when a source file's mtime is newer.  hipcc is replaced by a
+    recorder: the decision is what is under test."""
+    bm = _build_module()
+    calls = []
+
+    def fake_compile(out, extra_flags, verbose=False):
+        calls.append(out)
+        return out
+    monkeypatch.setattr(bm, "_compile", fake_compile)
+    lib = tmp_path / "libxgpr_hip.so"
+    monkeypatch.setattr(bm, "LIB", str(lib))
+    lib.write_bytes(b"\x7fELF....xgpr-build-id:" + b"0" * 64 + b"\0")          # newer than all sources, other id
+    bm.build_extension()
+    assert calls == [str(lib)]
+    lib.write_bytes(b"\x7fELF....xgpr-build-id:" + bm.source_id().encode() + b"\0")
+    os.utime(lib, (1, 1))                                                        # older than all sources, same id
+    bm.build_extension()
+    assert calls == [str(lib)]
+    lib.write_bytes(b"\x7fELF....no marker")
+    bm.build_extension()
+    assert len(calls) == 2
+
+
 def test_gfx950_code_object_present():
     """The shared library embeds a gfx950 code object (hipcc --offload-arch=gfx950)."""
     blob = open(os.path.join(ROOT, "xgpr_amd", "libxgpr_hip.so"), "rb").read()

@@ -1,0 +1,61 @@
+"""Compiler evidence as a test (no GPU): no kernel of the library uses scratch memory, no kernel's register-limited
+occupancy fell below the committed floor, and no inline-assembly statement loads into a register.
+
+Round 4's race fix in wave_conv_kernel left a 60-byte spill behind that nothing noticed; rounds 2-3 shipped a
+register-targeted global_load issued from inline assembly whose wait the compiler moved copies in front of.  Both
+classes are caught here: tools/resource_usage.py (hipcc -Rpass-analysis=kernel-resource-usage, ~50 s) and
+tools/lint_asm_loads.py."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# register-limited waves per SIMD the design relies on: the fused matvec, the convolution feature
+# operator and the feature operator run three / three / six waves per SIMD
+HOT = {"ztz3_kernel<10, 0>": 3, "ztz3_kernel<8, 0>": 3, "ztz3_kernel<10, 1>": 3, "wave_conv_kernel<8, 0>": 3,
+       "wave_conv_kernel<10, 0>": 3, "wave_rbf_kernel<10, 0>": 6}
+
+
+@pytest.fixture(scope="module")
+def rows():
+    import resource_usage
+    return resource_usage.collect()
+
+
+def test_no_kernel_uses_scratch(rows):
+    assert len(rows) > 200
+    bad = [(r["name"], r["ScratchSize"], r.get("VGPRs Spill")) for r in rows if r.get("ScratchSize", 0) or r.get("VGPRs Spill", 0)]
+    assert not bad, f"kernels with scratch / spilled VGPRs: {bad}"
+
+
+def test_occupancy_not_below_the_committed_floor(rows):
+    floor = json.load(open(os.path.join(ROOT, "tests", "golden", "resource_floor.json")))
+    got = {r["name"]: r["Occupancy"] for r in rows}
+    for name, occ in HOT.items():
+        assert got[name] >= occ, f"{name}: {got[name]} waves/SIMD, the design needs {occ}"
+    lost = {n: (floor[n], got[n]) for n in floor if n in got and got[n] < floor[n]}
+    assert not lost, f"occupancy fell (floor, now): {lost} -- fix the kernel or re-run tools/resource_usage.py --write-floor with a reason"
+    assert not [n for n in floor if n not in got], "kernels vanished: regenerate tests/golden/resource_floor.json"
+
+
+def test_no_inline_assembly_load_into_a_register():
+    import lint_asm_loads
+    assert lint_asm_loads.main() == 0
+
+
+def test_the_lint_catches_the_round_3_form(tmp_path):
+    import lint_asm_loads
+    f = tmp_path / "bad.inc"
+    f.write_text('''
+        // global_load_dword in a comment is fine
+        asm volatile("s_mov_b64 exec, %2\\n\\tglobal_load_dword %0, %1, %3 offset:%4\\n\\ts_mov_b64 exec, -1"
+                     : "+v"(t) : "v"(lane4), "s"(okm[r]), "s"(xe), "n"(r * 256) : "memory");
+        asm volatile("s_mov_b32 m0, %2\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
+        asm("ds_read_b32 %0, %1" : "=v"(x) : "v"(a));
+    ''')
+    found = [inst for _, _, inst in lint_asm_loads.offences(str(f))]
+    assert found == ["global_load_dword", "ds_read_b32"]

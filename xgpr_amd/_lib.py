@@ -75,7 +75,7 @@ SIZE_FUNCS = {
     "xgpr_sketch_gemm_workspace_bytes": [_l, _l, _l, _l, _i],
     "xgpr_ztz_gram_workspace_bytes": [_l, _l],
 }
-STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch"]
+STRING_FUNCS = ["xgpr_last_error", "xgpr_build_arch", "xgpr_build_id"]
 
 _lib = None
 
@@ -107,6 +107,11 @@ def load():
         fn.restype = C.c_char_p
     _lib = lib
     return lib
+
+
+def build_id():
+    """sha256 of the sources and flags the loaded library was compiled from (xgpr_amd/build.py source_id())."""
+    return load().xgpr_build_id().decode()
 
 
 def last_error():

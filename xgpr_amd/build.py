@@ -5,7 +5,9 @@
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the authoring container;
 the built .so travels to the GPU box with the repository snapshot.
 """
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -39,34 +41,62 @@ def sources():
     return [SRC, HDR] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".inc"))
 
 
+def source_id(extra_flags=()):
+    """sha256 over what determines the binary: every file of the translation unit (csrc/*, include/xgpr_hip.h: name and
+    contents, in sorted order) and the flag list.  Baked into the library at compile time (-DXGPR_BUILD_ID) and
+    returned by xgpr_build_id(): a .so states which tree it was built from, and build() rebuilds on a mismatch --
+    modification times are not consulted (a checkout of older sources leaves the .so NEWER than them)."""
+    h = hashlib.sha256()
+    for p in sorted(sources(), key=os.path.basename):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()
+
+
+def built_id(lib_path):
+    """The id a built library carries (read from the file's bytes: loading it here would bind the system HIP runtime
+    before torch's), or None."""
+    if not os.path.exists(lib_path):
+        return None
+    with open(lib_path, "rb") as f:
+        m = re.search(rb"xgpr-build-id:([0-9a-f]{64})", f.read())
+    return m.group(1).decode() if m else None
+
+
 def is_stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in sources())
+    return built_id(LIB) != source_id()
 
 
-def build_probe(force=False):
-    """Compile the VALU-only timing probe (see PROBE_LIB) if missing or older than its sources."""
-    if not force and os.path.exists(PROBE_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(PROBE_LIB) for p in sources()):
-        return PROBE_LIB
-    res = subprocess.run([hipcc_path()] + FLAGS + ["-DXGPR_ABL_VALUONLY", SRC, "-o", PROBE_LIB], capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed (probe):\n" + res.stdout + res.stderr)
-    return PROBE_LIB
-
-
-def build_extension(force=False, verbose=False):
-    """Compile csrc/xgpr_hip.hip -> libxgpr_hip.so if missing or older than its sources."""
-    if not force and not is_stale():
-        return LIB
-    cmd = [hipcc_path()] + FLAGS + [SRC, "-o", LIB]
+def _compile(out, extra_flags, verbose=False):
+    sid = source_id(extra_flags)
+    cmd = [hipcc_path()] + FLAGS + list(extra_flags) + ['-DXGPR_BUILD_ID="%s"' % sid, SRC, "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    return LIB
+    os.replace(out + ".tmp", out)          # a process that has the old file mapped keeps its copy
+    return out
+
+
+PROBE_FLAGS = ("-DXGPR_ABL_VALUONLY",)
+
+
+def build_probe(force=False):
+    """Compile the VALU-only timing probe (see PROBE_LIB) if missing or built from other sources."""
+    if not force and built_id(PROBE_LIB) == source_id(PROBE_FLAGS):
+        return PROBE_LIB
+    return _compile(PROBE_LIB, PROBE_FLAGS)
+
+
+def build_extension(force=False, verbose=False):
+    """Compile csrc/xgpr_hip.hip -> libxgpr_hip.so if missing or built from other sources / flags."""
+    if not force and not is_stale():
+        return LIB
+    return _compile(LIB, (), verbose)
 
 
 if __name__ == "__main__":

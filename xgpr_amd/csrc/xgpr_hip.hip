@@ -70,6 +70,16 @@ extern "C" {
 const char *xgpr_last_error(void) { return g_err.c_str(); }
 const char *xgpr_build_arch(void) { return "gfx950"; }
 
+// sha256 of the sources and flags this binary was compiled from (xgpr_amd/build.py source_id(), passed as
+// -DXGPR_BUILD_ID); the marker in front lets build.py read it from the file without loading the library
+#ifndef XGPR_BUILD_ID
+#define XGPR_BUILD_ID "unidentified"
+#endif
+const char *xgpr_build_id(void) {
+    static const char id[] = "xgpr-build-id:" XGPR_BUILD_ID;
+    return id + 14;
+}
+
 int xgpr_fht_f32(float *x, long n, long dim1, long dim2, void *stream) { return fht_impl<float>(x, n, dim1, dim2, stream); }
 int xgpr_fht_f64(double *x, long n, long dim1, long dim2, void *stream) { return fht_impl<double>(x, n, dim1, dim2, stream); }
 
