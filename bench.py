@@ -827,6 +827,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    torch.cuda.synchronize()
+    comm.close()                   # the direct RCCL communicator (if any): every rank is here, its stream is idle
     if comm.through_backend:
         torch.distributed.destroy_process_group()
     if loss_check["ok"] is False:

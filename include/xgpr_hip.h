@@ -164,6 +164,12 @@ int xgpr_conv1d_maxpool_f64(const double *x, float *out, const int8_t *radem, co
  * workspace still holds the masks of an earlier call with the same radem (a CG solve calls this once per
  * iteration with one workspace), and the packing launch is skipped. */
 size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2);
+/* Which plan xgpr_ztz_matvec_f32 runs for rows of d floats (16-byte aligned) and num_freqs frequencies -- what a caller
+ * that can also keep the features resident (xgpr_rbf_feature_cache_f32 + xgpr_zcache_matvec_f32) decides by:
+ * 1 = one pass, three waves per SIMD (regenerating is as fast as streaming the cache); 2 = one pass, two-wave kernel
+ * (one tile per datapoint, or a tile count that does not divide 12, or padded width < 128, or d % 4 != 0: slower than
+ * the cache stream); 3 = two feature passes (num_freqs > 8192); 0 = unsupported shape. */
+int xgpr_ztz_matvec_plan(long d, long num_freqs);
 int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v,
                         double *w_out, long n, long d, long num_rffs, long num_freqs,
                         long radem_shape2, int fit_intercept,
@@ -216,7 +222,8 @@ int xgpr_cg_step2_block_f64(const double *r_next, const double *z_next, const do
 /* The classifier's cost function between its projection and back-projection
  * (src/xGPR/fitting_toolkit/nonlinear_cg_toolkit.py:243-262): pred [n, ncls] float64 row-major is replaced, row by row,
  * by softmax_2.71828(pred) - onehot(label); loss_partials [ceil(n / 256)] receives per-workgroup sums of
- * -log(max(p[label], 1e-16)) (the caller adds them); labels int64 [n] in [0, ncls). */
+ * -log(max(p[label], 1e-16)) (the caller adds them); labels int64 [n] in [0, ncls) -- a label outside that range makes its
+ * workgroup's partial NaN (the reference's gather / scatter fails on such an index). */
 int xgpr_softmax_residual_f64(double *pred, const long *labels, long n, long ncls, double *loss_partials, void *stream);
 
 /* The first product of RandNysPreconditioner.batch_matvec for a block of right-hand sides
@@ -350,10 +357,16 @@ int xgpr_zcache_block_matvec_f32(const float *zc, const double *v, double *w_out
  * predict (xgp_classification.py:96-102):
  *   project:      t_out[n, k]        =  Z v        v     [num_rffs, k]
  *   backproject:  g_out[num_rffs, k] (+)= Z^T r    r     [n, k]
- * with Z = scale * zc and Z[:,0] = 1 under fit_intercept; all float64, C-contiguous.  The projection
- * needs no workspace; the back-projection takes xgpr_zcache_block_workspace_bytes(n, num_rffs, k). */
+ * with Z = scale * zc and Z[:,0] = 1 under fit_intercept; all float64, C-contiguous.  The back-projection takes
+ * xgpr_zcache_block_workspace_bytes(n, num_rffs, k).  The projection runs with workspace == NULL; given
+ * xgpr_zcache_block_project_workspace_bytes(n, num_rffs, k) (0 for long launches; a workspace sized for the
+ * back-projection is large enough), a short launch (fewer than 65536 rows: a chunk of ~2000 rows is what the reference
+ * feeds it, cg_tools.py:41-44) splits the contraction over the features across workgroups and adds the partial sums in
+ * a fixed order -- deterministic for a given (n, num_rffs, k). */
+size_t xgpr_zcache_block_project_workspace_bytes(long n, long num_rffs, long k);
 int xgpr_zcache_block_project_f32(const float *zc, const double *v, double *t_out, long n, long num_rffs,
-                                  long k, int fit_intercept, double scale, void *stream);
+                                  long k, int fit_intercept, double scale,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 int xgpr_zcache_block_backproject_f32(const float *zc, const double *r, double *g_out, long n, long num_rffs,
                                       long k, int fit_intercept, double scale, int accumulate,
                                       void *workspace, size_t workspace_bytes, void *stream);

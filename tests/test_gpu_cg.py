@@ -234,25 +234,40 @@ def test_batched_rhs_cg_matches_oracle(oracle):
     assert rel(xk, xref) < 1e-6
 
 
-def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_faster():
-    """cache_features="auto": one right-hand side and a single feature pass (num_freqs <= 8192) regenerates -- the
-    fused kernel is at least as fast as the HBM stream of the cache; two feature passes (num_freqs > 8192), a block of
-    right-hand sides, or a convolution kernel keep the float32 features resident (when they fit)."""
+def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_faster(monkeypatch):
+    """cache_features="auto" follows the matvec launcher's own plan (xgpr_ztz_matvec_plan): one right-hand side on the
+    single-pass three-wave kernel regenerates (a long shard: at least as fast as the HBM stream of the cache); every
+    other plan -- the two-wave kernel (one tile per datapoint, 8 tiles, padded width < 128, d % 4 != 0), two feature
+    passes (num_freqs > 8192) --, a short shard, a block of right-hand sides or a convolution kernel keep the float32
+    features resident (when they fit).  Measured: tools/cache_rule_probe.py."""
     from xgpr_amd.kernels import make_kernel
     from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd import cg as cgmod, xgpr_hip_rfgen_ext as ext
     from xgpr_amd.cg import _resolve_cache_mode
     rng = np.random.default_rng(0)
-    x = rng.standard_normal((256, 64)).astype(np.float32)
-    ds = build_regression_dataset(x, rng.standard_normal(256), chunk_size=128, device=DEV)
-    small = make_kernel("RBF", x.shape, 4096, 123, DEV, {})
-    wide = make_kernel("RBF", x.shape, 32768, 123, DEV, {})
-    for k in (small, wide):
+    assert [ext.ztz_matvec_plan(d, f) for d, f in ((1024, 4096), (256, 2048), (256, 1024), (1024, 8192), (512, 5120),
+                                                    (64, 2048), (20, 1024), (1022, 4096), (512, 16384), (2000, 4096))] == \
+        [1, 1, 2, 2, 2, 2, 2, 2, 3, 0]
+    monkeypatch.setattr(cgmod, "SMALL_SHARD_ROWS", 100)          # the 256-row shards below count as long ones
+    pays = {}
+    for d, m in ((256, 4096), (256, 2048), (1024, 16384), (64, 4096), (20, 2048), (254, 4096), (256, 32768)):
+        x = rng.standard_normal((256, d)).astype(np.float32)
+        ds = build_regression_dataset(x, rng.standard_normal(256), chunk_size=128, device=DEV)
+        k = make_kernel("RBF", x.shape, m, 123, DEV, {})
         k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
-    assert small.cache_ok() and not small.cache_pays() and wide.cache_pays()
-    assert _resolve_cache_mode("auto", small, ds) is False
-    assert _resolve_cache_mode("auto", wide, ds) is True
-    assert _resolve_cache_mode("auto", small, ds, block=True) is True
-    assert _resolve_cache_mode(True, small, ds) is True and _resolve_cache_mode(False, wide, ds) is False
+        assert k.cache_ok()
+        pays[(d, m)] = k.cache_pays()
+        assert _resolve_cache_mode("auto", k, ds) is k.cache_pays()
+        assert _resolve_cache_mode("auto", k, ds, block=True) is True
+        assert _resolve_cache_mode(True, k, ds) is True and _resolve_cache_mode(False, k, ds) is False
+    assert pays == {(256, 4096): False, (256, 2048): True, (1024, 16384): True, (64, 4096): True, (20, 2048): True,
+                    (254, 4096): True, (256, 32768): True}
+    monkeypatch.setattr(cgmod, "SMALL_SHARD_ROWS", 200_000)      # ... and as short ones: the stream's smaller cost per launch wins
+    x = rng.standard_normal((256, 256)).astype(np.float32)
+    ds = build_regression_dataset(x, rng.standard_normal(256), chunk_size=128, device=DEV)
+    k = make_kernel("RBF", x.shape, 4096, 123, DEV, {})
+    k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+    assert not k.cache_pays() and _resolve_cache_mode("auto", k, ds) is True
 
 
 def test_cg_with_resident_feature_cache_matches_regenerating_cg():

@@ -45,6 +45,56 @@ def test_project_and_backproject_vs_float64_product(n, m, k, icpt):
     assert rel(t, (0.5 * zc.double() @ v).cpu().numpy()) < 1e-13
 
 
+@pytest.mark.parametrize("n,m,k,icpt", [(133, 1024, 3, True), (2048, 8192, 26, True), (2000, 8192, 10, False), (5000, 4100, 32, True),
+                                        (16384, 2048, 17, True), (300, 640, 1, True)])
+def test_short_projection_splits_the_contraction_and_stays_exact(n, m, k, icpt, monkeypatch):
+    """Launches of fewer than 65536 rows (the reference's chunk is ~2000 rows, cg_tools.py:41-44) split the contraction
+    over the features across workgroups (zblock_t_kernel, blockIdx.y) and add the partials in split order: the result
+    is the float64 product to rounding, the same bits on every call, and equal to the unsplit kernel's (workspace
+    None at the C ABI) to a few ulps of the row sums."""
+    import ctypes as C
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext, _lib
+    g = torch.Generator(device=DEV).manual_seed(n + m + k)
+    zc = torch.rand((n, m), dtype=torch.float32, device=DEV, generator=g) * 2 - 1
+    v = torch.randn((m, k), dtype=torch.float64, device=DEV, generator=g)
+    scale = float(np.float32(np.sqrt(1.0 / (m // 2 - 0.5 if icpt else m // 2))))
+    z = zc.double() * scale
+    if icpt:
+        z[:, 0] = 1.0
+    ref = (z @ v).cpu().numpy()
+    need = ext.zcache_block_project_workspace_bytes(n, m, k)
+    assert (need > 0) == (m >= 1024), "these shapes are short launches: all but the narrowest split"
+    assert ext.zcache_block_workspace_bytes(n, m, k) >= need
+    t = torch.full((n, k), 3.0, dtype=torch.float64, device=DEV)
+    ext.hipZCacheBlockProject(zc, v, t, icpt)
+    assert rel(t, ref) < 1e-13
+    t2 = torch.full((n, k), -1.0, dtype=torch.float64, device=DEV)
+    ws = torch.full((max(need, 16),), 0xFF, dtype=torch.uint8, device=DEV)          # a poisoned workspace: every partial is written before it is read
+    ext.hipZCacheBlockProject(zc, v, t2, icpt, 0.0, ws)
+    assert torch.equal(t, t2)
+    # the unsplit kernel: no workspace at the C ABI
+    t3 = torch.empty_like(t)
+    lib = _lib.load()
+    _lib.check(lib.xgpr_zcache_block_project_f32(C.c_void_p(zc.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(t3.data_ptr()),
+                                                 n, m, k, int(icpt), 0.0, None, C.c_size_t(0), None))
+    torch.cuda.synchronize()
+    assert rel(t3, ref) < 1e-13 and rel(t3, t.cpu().numpy()) < 1e-14
+    if need:
+        small = torch.empty(need - 16, dtype=torch.uint8, device=DEV)
+        with pytest.raises(RuntimeError):
+            ext.hipZCacheBlockProject(zc, v, t2, icpt, 0.0, small)
+    # the block matvec of a short shard runs the same split T kernel in front of the W kernel
+    if k <= 32 and m % 4 == 0:
+        w = torch.empty((m, k), dtype=torch.float64, device=DEV)
+        bws = torch.empty(ext.zcache_block_workspace_bytes(n, m, k), dtype=torch.uint8, device=DEV)
+        ext.hipZCacheBlockMatvec(zc, v, w, icpt, bws)
+        refw = (z.T @ (z @ v)).cpu().numpy()
+        assert rel(w, refw) < 1e-13
+        w2 = torch.empty_like(w)
+        ext.hipZCacheBlockMatvec(zc, v, w2, icpt, bws)
+        assert torch.equal(w, w2)
+
+
 @pytest.mark.parametrize("cache", [False, True])
 def test_g11_classifier_vs_reference(cache):
     from xgpr_amd.kernels import make_kernel
@@ -156,3 +206,8 @@ def test_softmax_residual_kernel_equals_the_reference_chain(n, ncls):
     assert abs(float(loss) - float(loss_ref)) <= 1e-12 * abs(float(loss_ref))
     out2 = pred.clone()
     assert torch.equal(ext.hipSoftmaxResidual(out2, labels), loss) and torch.equal(out2, out)      # reproducible
+    # a label outside [0, classes) is not dropped silently: the loss turns NaN (the reference's gather raises)
+    for badlab in (ncls, -1):
+        bad = labels.clone()
+        bad[n // 2] = badlab
+        assert torch.isnan(ext.hipSoftmaxResidual(pred.clone(), bad)).all()

@@ -68,9 +68,46 @@ for n in rows_list:
                                   "loop_us_mean": round(us((tl - tp)[sel].mean()), 2), "loop_us_max": round(us((tl - tp)[sel].max()), 2),
                                   "end_us_max": round(us((t1[sel] - first).max()), 2),
                                   "clock_ghz": round(float((lcyc[sel] / ((tl - tp)[sel] * 10)).mean()), 3)}
+    # clock against time inside the launch (workgroup 0: samples every 8 datapoints)
+    ns = (iters + 7) // 8
+    smp = ws[off + 2 * F * 8: off + 2 * F * 8 + 8 * 512 * 8].view(torch.float64).reshape(8, 256, 2).cpu().numpy()[:, :ns, :]
+    curve = []
+    for j in range(1, ns):
+        dt_us = (smp[0, j, 0] - smp[0, j - 1, 0]) / 100.0
+        curve.append({"t_us": round((smp[0, j, 0] - t0[0]) / 100.0, 1), "us_per_datapoint": round(dt_us / 8, 3),
+                      "clock_ghz": round(float((smp[0, j, 1] - smp[0, j - 1, 1]) / (dt_us * 1e3)), 3)})
+    ent["workgroup0_clock_curve"] = curve[:24] + (curve[24::8] if len(curve) > 24 else [])
     res["rows"][str(n)] = ent
-    print(n, json.dumps({k: ent[k] for k in ent if k != "per_xcc"}))
+    print(n, json.dumps({k: ent[k] for k in ent if k not in ("per_xcc", "workgroup0_clock_curve")}))
     print("   per XCC:", json.dumps(ent["per_xcc"]))
+    print("   clock curve:", " ".join("%g:%.2f/%.2f" % (c["t_us"], c["clock_ghz"], c["us_per_datapoint"]) for c in ent["workgroup0_clock_curve"]))
+# does the launch slow down when the device idles in front of it?  One matvec timed by its own pair of events behind a gap
+# in which one wave spins (torch.cuda._sleep) and the other 255 CUs idle
+n = 125000 if 125000 in rows_list else rows_list[0]
+xs = xall[:n]
+kern = make_kernel("Matern", (n, d), m, 123, dev, {"matern_nu": 2.5})
+kern.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+v = torch.randn(m, dtype=torch.float64, device=dev, generator=g)
+w = torch.empty_like(v)
+ws = torch.zeros(kern.workspace_bytes(), dtype=torch.uint8, device=dev)
+gaps = {}
+for gap_us in (0, 20, 50, 100, 200, 500, 2000):
+    for _ in range(5):
+        kern.ztz_matvec(xs, v, w, ws)
+    ts = []
+    for _ in range(20):
+        eg = torch.cuda.Event(enable_timing=True); eg.record()
+        if gap_us:
+            torch.cuda._sleep(int(gap_us * 2100))          # ~cycles at 2.1 GHz (the measured gap is reported)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); kern.ztz_matvec(xs, v, w, ws); e1.record()
+        ts.append((eg, e0, e1))
+    torch.cuda.synchronize()
+    t = np.array([a.elapsed_time(b) * 1e3 for _, a, b in ts])
+    gm = float(np.median([a.elapsed_time(b) * 1e3 for a, b, _ in ts]))
+    gaps[str(gap_us)] = {"measured_gap_us": round(gm, 1), "matvec+reduce_us_p50": round(float(np.median(t)), 1), "min": round(float(t.min()), 1)}
+    print("idle gap %5d us requested, %.1f measured: launch %.1f us (min %.1f)" % (gap_us, gm, np.median(t), t.min()))
+res["idle_gap_in_front_of_a_125000_row_launch"] = gaps
 if out_file:
     with open(out_file, "w") as f:
         json.dump(res, f, indent=1)

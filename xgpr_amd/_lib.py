@@ -49,12 +49,13 @@ SIGNATURES = {
     "xgpr_zcache_matvec_f32": [_vp, _vp, _vp, _l, _l, _i, _vp, _sz, _vp],
     "xgpr_zcache_matvec_scaled_f32": [_vp, _vp, _vp, _l, _l, _d, _vp, _sz, _vp],
     "xgpr_zcache_block_matvec_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _i, _vp, _sz, _vp],
-    "xgpr_zcache_block_project_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _vp],
+    "xgpr_zcache_block_project_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _vp, _sz, _vp],
     "xgpr_zcache_block_backproject_f32": [_vp, _vp, _vp, _l, _l, _l, _i, _d, _i, _vp, _sz, _vp],
     "xgpr_srht_sample_rows_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _l, _l, _d, _i, _vp, _sz, _vp],
     "xgpr_sketch_gemm_f64": [_vp, _l, _vp, _l, _l, _vp, _l, _l, _i, _i, _d, _i, _i, _vp, _sz, _vp],
     "xgpr_ztz_gram_f64": [_vp, _l, _l, _vp, _l, _l, _d, _i, _i, _vp, _sz, _vp],
     "xgpr_selftest_lane_xor": [_vp, _vp],
+    "xgpr_ztz_matvec_plan": [_l, _l],
     "xgpr_rccl_load": [C.c_char_p],
     "xgpr_rccl_unique_id": [_vp],
     "xgpr_rccl_comm_init": [_vp, _i, _vp, _i],
@@ -71,6 +72,7 @@ SIZE_FUNCS = {
     "xgpr_cg_block_workspace_bytes": [_l, _l],
     "xgpr_ztz_matvec_workspace_bytes": [_l, _l],
     "xgpr_zcache_block_workspace_bytes": [_l, _l, _l],
+    "xgpr_zcache_block_project_workspace_bytes": [_l, _l, _l],
     "xgpr_srht_sample_workspace_bytes": [_l],
     "xgpr_sketch_gemm_workspace_bytes": [_l, _l, _l, _l, _i],
     "xgpr_ztz_gram_workspace_bytes": [_l, _l],

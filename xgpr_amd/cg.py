@@ -468,6 +468,9 @@ class ConjugateGrad:
         return x_k[:, 0], converged, niter + 1, losses
 
 
+SMALL_SHARD_ROWS = 200_000
+
+
 def _resolve_cache_mode(cache_features, kernel, dataset, block=False):
     """"auto": keep Z resident when the kernel supports it, when streaming it is faster than regenerating it
     (``kernel.cache_pays``; always for a block of right-hand sides) and the float32 cache of this shard fits
@@ -479,7 +482,12 @@ def _resolve_cache_mode(cache_features, kernel, dataset, block=False):
     if supported is None or not supported() or torch.device(kernel.device).type != "cuda":
         return False
     if not block and hasattr(kernel, "cache_pays") and not kernel.cache_pays():
-        return False          # one right-hand side, single-pass fused kernel: regenerating is at least as fast (kernels.py)
+        # One right-hand side on the single-pass three-wave kernel: regenerating is at least as fast as the stream for a
+        # long shard (kernels.py) -- but the stream has the smaller cost per launch, and below ~250 000 rows it wins:
+        # 0.746 against 0.776 ms per iteration on a 125 000-row shard (cfg3 over 8 GPUs), 1.401 / 1.400 at 250 000,
+        # 2.731 / 2.636 at 500 000 (gpurun_out/r4/shard_*.json, `cached_z_mode`).
+        if dataset.get_local_ndatapoints() > SMALL_SHARD_ROWS:
+            return False
     free, _total = torch.cuda.mem_get_info(torch.device(kernel.device))
     return 1.5 * dataset.feature_cache_bytes(kernel) + 2e9 < free
 

@@ -91,6 +91,11 @@ class NonlinearCGClassification:
         """nonlinear_cg_toolkit.py:231-275 -> (grad [M, classes], loss)."""
         dev = wvec.device
         m, ncls = wvec.shape
+        # labels are validated where the dataset is built (zero category, global maximum = n_classes - 1); the weight
+        # block must cover them: the fused softmax / residual kernel indexes classes by label (an uncovered label would
+        # drop out of the loss; the kernel returns NaN for it, this is the message)
+        if self.dataset.get_n_classes() > ncls:
+            raise RuntimeError(f"labels run to {self.dataset.get_n_classes() - 1} but the weights have {ncls} class columns")
         wvec = wvec.contiguous()
         grad = torch.zeros_like(wvec)
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -117,10 +122,10 @@ class NonlinearCGClassification:
             for j0 in range(0, ncls, 32):                     # 32 columns per call of the block operators
                 j1 = min(ncls, j0 + 32)
                 if j0 == 0 and j1 == ncls:
-                    ext.hipZCacheBlockProject(zc, wvec, pred, icpt, scale)
+                    ext.hipZCacheBlockProject(zc, wvec, pred, icpt, scale, self._ws)
                 else:
                     part = torch.empty((n, j1 - j0), dtype=torch.float64, device=dev)
-                    ext.hipZCacheBlockProject(zc, wvec[:, j0:j1].contiguous(), part, icpt, scale)
+                    ext.hipZCacheBlockProject(zc, wvec[:, j0:j1].contiguous(), part, icpt, scale, self._ws)
                     pred[:, j0:j1] = part
             # row maximum, 2.71828 ** (.) (the reference's constant, not e), normalisation, loss and residual: one launch
             loss += ext.hipSoftmaxResidual(pred, labels.to(torch.int64).contiguous())

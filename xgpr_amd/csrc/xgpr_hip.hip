@@ -196,6 +196,12 @@ int xgpr_conv1d_maxpool_f64(const double *x, float *out, const int8_t *radem, co
 size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2) {
     return ztz_workspace_bytes(num_rffs, radem_shape2);
 }
+int xgpr_ztz_matvec_plan(long d, long num_freqs) {
+    const long P = padded_width(d);
+    if (P > 1024 || num_freqs < 1 || num_freqs > 65536) return 0;
+    if (num_freqs > 8192) return 3;
+    return ztz3_shape_ok(d, P, (int)((num_freqs + 1023) / 1024)) ? 1 : 2;
+}
 int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v, double *w_out,
                         long n, long d, long num_rffs, long num_freqs, long radem_shape2, int fit_intercept,
                         void *workspace, size_t workspace_bytes, void *stream) {
@@ -387,7 +393,11 @@ int xgpr_zcache_matvec_scaled_f32(const float *zc, const double *v, double *w_ou
 size_t xgpr_zcache_block_workspace_bytes(long n, long num_rffs, long k) {
     if (n <= 0 || num_rffs <= 0 || k < 1) return 0;
     const ZbGeom gm = zb_geometry(n, num_rffs, k > 32 ? 32 : k);
-    return gm.t_bytes + gm.slab_bytes;
+    return gm.t_bytes + gm.slab_bytes + gm.tpart_bytes;
+}
+size_t xgpr_zcache_block_project_workspace_bytes(long n, long num_rffs, long k) {
+    if (n <= 0 || num_rffs <= 0 || k < 1) return 0;
+    return zb_geometry(n, num_rffs, k > 32 ? 32 : k).tpart_bytes;
 }
 int xgpr_zcache_block_matvec_f32(const float *zc, const double *v, double *w_out, long n, long num_rffs, long k,
                                  int fit_intercept, double scale, int accumulate, void *workspace,
@@ -396,8 +406,9 @@ int xgpr_zcache_block_matvec_f32(const float *zc, const double *v, double *w_out
                              workspace_bytes, stream);
 }
 int xgpr_zcache_block_project_f32(const float *zc, const double *v, double *t_out, long n, long num_rffs, long k,
-                                  int fit_intercept, double scale, void *stream) {
-    return zcache_block_impl(ZB_PROJECT, zc, v, t_out, n, num_rffs, k, fit_intercept, scale, 0, nullptr, 0, stream);
+                                  int fit_intercept, double scale, void *workspace, size_t workspace_bytes, void *stream) {
+    return zcache_block_impl(ZB_PROJECT, zc, v, t_out, n, num_rffs, k, fit_intercept, scale, 0, workspace, workspace_bytes,
+                             stream);
 }
 int xgpr_zcache_block_backproject_f32(const float *zc, const double *r, double *g_out, long n, long num_rffs, long k,
                                       int fit_intercept, double scale, int accumulate, void *workspace,

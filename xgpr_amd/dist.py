@@ -109,17 +109,27 @@ class Comm:
         if not all_agree(ok):
             self.close()
         else:
-            atexit.register(self.close)
+            atexit.register(self._abandon)
         return self._rccl is not None
 
     def close(self):
-        """Destroy the direct communicator (if any); the sums go back to torch.distributed.  Local, idempotent."""
+        """Destroy the direct communicator (if any); the sums go back to torch.distributed.  Local, idempotent.
+        The owner calls this at an orderly point: every rank alive, the stream the last all-reduce was queued on
+        synchronised (done here for CUDA), BEFORE torch.distributed.destroy_process_group()."""
         handle, self._rccl = self._rccl, None
         if handle is not None:
             try:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 self._rccl_lib.xgpr_rccl_comm_destroy(handle)
             except (RuntimeError, OSError, AttributeError):
                 pass
+
+    def _abandon(self):
+        """Interpreter exit without close(): the handle is dropped, NOT destroyed -- ncclCommDestroy at that point runs
+        after destroy_process_group(), possibly after a peer has died, with work of unknown state on the stream, and can
+        turn an error exit into a hang; the process is going away and takes the communicator with it."""
+        self._rccl = None
 
     def _direct_sum(self, tensor):
         rc = self._rccl_lib.xgpr_allreduce_sum_f64(self._rccl, ctypes.c_void_p(tensor.data_ptr()), tensor.numel(),

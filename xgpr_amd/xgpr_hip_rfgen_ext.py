@@ -630,17 +630,24 @@ def hipZCacheBlockMatvec(cacheArr, vecs, outVecs, fitIntercept, workspace, scale
         int(bool(accumulate)), C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
 
 
-def hipZCacheBlockProject(cacheArr, vecs, outArr, fitIntercept, scale=0.0):
+def hipZCacheBlockProject(cacheArr, vecs, outArr, fitIntercept, scale=0.0, workspace=None):
     """``outArr[n, k] = Z @ vecs`` (the classifier's ``xd @ wvec``, nonlinear_cg_toolkit.py:251) on the
-    float64 matrix cores over the float32 feature rows."""
+    float64 matrix cores over the float32 feature rows.  ``workspace`` (zcache_block_project_workspace_bytes; allocated
+    here when a short launch would use one and none is passed) lets launches of fewer than 65536 rows split the
+    contraction over the features across workgroups."""
     zc = _dev(cacheArr, "cacheArr", torch.float32, 2)
     v = _dev(vecs, "vecs", torch.float64, 2)
     o = _dev(outArr, "outArr", torch.float64, 2)
     if vecs.shape[0] != cacheArr.shape[1] or tuple(outArr.shape) != (cacheArr.shape[0], vecs.shape[1]):
         raise TypeError("vecs: expected [num_rffs, k]; outArr: expected [n, k]")
+    if workspace is None:
+        need = zcache_block_project_workspace_bytes(cacheArr.shape[0], cacheArr.shape[1], vecs.shape[1])
+        if need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=cacheArr.device)
+    wp, wn = (C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel())) if workspace is not None else (None, C.c_size_t(0))
     return _lib.check(_LIB.xgpr_zcache_block_project_f32(
         zc, v, o, cacheArr.shape[0], cacheArr.shape[1], vecs.shape[1], int(bool(fitIntercept)), float(scale),
-        _stream()))
+        wp, wn, _stream()))
 
 
 def hipZCacheBlockBackproject(cacheArr, resid, outVecs, fitIntercept, workspace, scale=0.0, accumulate=False):
@@ -656,12 +663,22 @@ def hipZCacheBlockBackproject(cacheArr, resid, outVecs, fitIntercept, workspace,
         int(bool(accumulate)), C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel()), _stream()))
 
 
+def zcache_block_project_workspace_bytes(ndatapoints, num_rffs, k):
+    return int(_LIB.xgpr_zcache_block_project_workspace_bytes(ndatapoints, num_rffs, k))
+
+
 def zcache_block_workspace_bytes(ndatapoints, num_rffs, k):
     return int(_LIB.xgpr_zcache_block_workspace_bytes(ndatapoints, num_rffs, k))
 
 
 def ztz_workspace_bytes(num_rffs, radem_shape2):
     return int(_LIB.xgpr_ztz_matvec_workspace_bytes(num_rffs, radem_shape2))
+
+
+def ztz_matvec_plan(d, num_freqs):
+    """1: single pass on the three-wave kernel, 2: single pass on the two-wave kernel, 3: two feature passes, 0: unsupported
+    (xgpr_ztz_matvec_plan; no device work)."""
+    return int(_LIB.xgpr_ztz_matvec_plan(int(d), int(num_freqs)))
 
 
 def selftest_lane_xor(device="cuda"):
