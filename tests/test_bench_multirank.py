@@ -176,3 +176,75 @@ def test_one_sided_rccl_init_failure_drops_the_direct_path_on_both_ranks(tmp_pat
         log = list(r["log"])
         assert "direct_sum" not in log                   # nobody issued a collective on the half-made communicator
         assert log == (["init"] if rank == fail_rank else ["init", "destroy"])
+
+
+# ---- the follow-up job that rehearses the opt-in direct RCCL path (bench.direct_rccl_child): started after the main line,
+# watched, and never able to change the parent's stdout / exit code
+class _Args:
+    gpus, warmup, rows, dim, rffs, rank_precond = 2, 1, 2400, 16, 64, 8
+
+
+def _child_line():
+    return {"n_gpus": 2, "ms_per_step": 1.25, "value": 3.0e9, "final_loss": 0.5, "build_id": "ab" * 32,
+            "final_loss_check": {"expected": 0.5, "rtol": 1e-5, "ok": True},
+            "distributed": {"n_ranks_seen": 2, "allreduce_path": "xgpr_allreduce_sum_f64", "direct_equals_torch_allreduce": True,
+                            "allreduce_w_us_back_to_back": 21.0,
+                            "per_rank": [{"rank": 0, "allreduce_ms_per_iter": 0.02}, {"rank": 1, "allreduce_ms_per_iter": 0.021}]}}
+
+
+def test_direct_child_is_started_with_the_opt_in_and_its_line_is_recorded(tmp_path, capsys, monkeypatch):
+    import json
+    import bench
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("MASTER_PORT", "1")
+    prog = ("import os, json, sys\n"
+            "assert os.environ['XGPR_RCCL_DIRECT'] == '1' and os.environ['XGPR_BENCH_CHILD'] == '1'\n"
+            "assert not any(k in os.environ for k in ('RANK', 'WORLD_SIZE', 'MASTER_PORT', 'LOCAL_RANK'))   # a fresh job: it starts its own ranks\n"
+            "print('noise before the line'); print(json.dumps(%r)); sys.stderr.write('child stderr')\n" % (_child_line(),))
+    side = tmp_path / "child.json"
+    rec = bench.direct_rccl_child(_Args, limit_s=30, cmd=[sys.executable, "-c", prog.replace("True", "True")], side_file=str(side))
+    assert rec["status"] == "exited 0"
+    assert rec["line"]["direct_equals_torch_allreduce"] is True and rec["line"]["final_loss_check"]["ok"] is True
+    assert rec["line"]["allreduce_ms_per_iter"] == [0.02, 0.021] and rec["line"]["n_ranks_seen"] == 2
+    assert json.load(open(side))["line"]["ms_per_step"] == 1.25
+    cap = capsys.readouterr()
+    assert cap.out == "" and "direct-rccl child:" in cap.err           # stdout belongs to the ONE JSON line of the main job
+
+
+def test_direct_child_that_hangs_is_killed_with_its_whole_process_group(tmp_path, capsys):
+    import time
+    import bench
+    pidfile = tmp_path / "grandchild.pid"
+    # the child starts a grandchild (as torchrun starts the ranks) and both sleep for ever, ignoring SIGTERM
+    prog = ("import os, signal, subprocess, sys, time\n"
+            "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+            "p = subprocess.Popen([sys.executable, '-c', 'import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(1000)'])\n"
+            "open(%r, 'w').write(str(p.pid))\n"
+            "time.sleep(1000)\n" % str(pidfile))
+    t0 = time.perf_counter()
+    rec = bench.direct_rccl_child(_Args, limit_s=3, cmd=[sys.executable, "-c", prog], side_file=str(tmp_path / "c.json"))
+    assert time.perf_counter() - t0 < 40
+    assert rec["status"].startswith("timed out after 3 s") and rec["line"] is None
+    gpid = int(open(pidfile).read())
+    for _ in range(50):
+        try:
+            os.kill(gpid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        pytest.fail("the hung child's rank process survived the watchdog")
+    assert capsys.readouterr().out == ""
+
+
+def test_direct_child_failures_never_escape(tmp_path, capsys):
+    import bench
+    rec = bench.direct_rccl_child(_Args, limit_s=5, cmd=["/nonexistent/python"], side_file=str(tmp_path / "a.json"))
+    assert rec["status"].startswith("not started")
+    rec = bench.direct_rccl_child(_Args, limit_s=20, cmd=[sys.executable, "-c", "import sys; print('no json here'); sys.exit(3)"],
+                                  side_file=str(tmp_path / "b.json"))
+    assert rec["status"] == "exited 3" and rec["line"] is None
+    rec = bench.direct_rccl_child(_Args, limit_s="not a number", cmd=[sys.executable, "-c", "pass"], side_file="/proc/nope/x.json")
+    assert rec["status"].startswith("error in the parent")
+    assert capsys.readouterr().out == ""
