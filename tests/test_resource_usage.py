@@ -32,6 +32,15 @@ def test_no_kernel_uses_scratch(rows):
     assert not bad, f"kernels with scratch / spilled VGPRs: {bad}"
 
 
+def test_hot_kernels_spill_no_scalar_registers(rows):
+    """SGPR spills go to VGPR lanes (v_writelane / v_readlane: vector instructions in kernels the vector pipe bounds): the
+    three-wave kernel and the convolution feature operator hold 32 SGPRs of lane masks (fused_ztz.inc, Z3_SGPR_FLIP_ROUNDS)
+    and must still fit."""
+    bad = [(r["name"], r["SGPRs Spill"]) for r in rows
+           if (r["name"].startswith("ztz3_kernel") or r["name"].startswith("wave_conv_kernel")) and r.get("SGPRs Spill", 0)]
+    assert not bad, bad
+
+
 def test_occupancy_not_below_the_committed_floor(rows):
     floor = json.load(open(os.path.join(ROOT, "tests", "golden", "resource_floor.json")))
     got = {r["name"]: r["Occupancy"] for r in rows}
