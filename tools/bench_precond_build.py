@@ -26,4 +26,6 @@ for it in range(2):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     passes = 1 if method == "srht" else int(method.split("_")[1])
     fl = 2.0 * rows * rank * m * (1 if method == "srht" else 1 + 2 * (passes - 1))
-    print(f"rows={rows} d={d} M={m} rank={rank} {method}: {dt*1e3:.1f} ms  ({dt/rows*1e6:.3f} us/row, GEMM work alone {fl/dt/1e12:.1f} TFLOP/s) ratio={pre.achieved_ratio:.3g}")
+    print(f"rows={rows} d={d} M={m} rank={rank} {method}: {dt*1e3:.1f} ms  ({dt/rows*1e6:.3f} us/row, GEMM work alone {fl/dt/1e12:.1f} TFLOP/s) ratio={pre.achieved_ratio:.6g} "
+          f"checksums eig {float(pre.inv_eig.sum()):.15e} |U| {float(pre.u_mat.abs().sum()):.15e} zty {float(pre.get_zty().sum()):.15e}  "
+          f"(XGPR_PRECOND_PIPELINE={os.environ.get('XGPR_PRECOND_PIPELINE', '1')})")

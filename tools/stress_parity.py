@@ -35,7 +35,7 @@ for case in range(cases):
         n = int(rng.integers(20000, 60000))      # a launch that fills the chip: loads and stores in flight everywhere
     icpt = bool(rng.integers(0, 2))
     radem, chi = orc.draw_sorf_params(rffs, d, int(rng.integers(1, 1000)))
-    x = (rng.standard_normal((n, d)) / np.sqrt(d) * rng.choice([1.0, 1.0, 30.0])).astype(np.float32)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d) * rng.choice([1.0, 1.0, 30.0, 3e5, 1e15])).astype(np.float32)     # (the last two: the rare cos/sin branch, beyond 2^31)
     z = np.zeros((n, rffs))
     oracle.cpuRBFFeatureGen(x.copy(), z, radem, chi, icpt)
     F = rffs // 2
