@@ -54,6 +54,23 @@ class ConjugateGrad:
         self._ws_masks_of = None     # the radem tensor whose sign masks the workspace holds
         self._bws = None
         self._zwin = None
+        self._err_pinned = None      # pinned host slots the step kernels write their errors into (reused across solves)
+
+    def _pinned_errors(self, *shape):
+        """A pinned float64 array of ``shape`` filled with -1 (the "not written yet" mark).  One allocation per solver
+        object, grown in powers of two: hipHostMalloc takes from a fraction of a millisecond to a few milliseconds
+        depending on the host, and a solve of 20 iterations that pays it inside its timed region loses 1-4 % to it."""
+        need = 1
+        for dim in shape:
+            need *= int(dim)
+        if self._err_pinned is None or self._err_pinned.numel() < need:
+            cap = 1024
+            while cap < need:
+                cap *= 2
+            self._err_pinned = torch.empty(cap, dtype=torch.float64).pin_memory()
+        view = self._err_pinned[:need].view(*shape)
+        view.fill_(-1.0)
+        return view
 
     def _matvec(self, dataset, kernel, vec, matvec, add_ridge=True):
         """cg_tools.py:173-200 (regression branch): matvec <- (Z^T Z + lambda^2) vec (``add_ridge=False``: the
@@ -184,7 +201,7 @@ class ConjugateGrad:
         # errors arrive in pinned host memory, written by cg_step1_kernel itself (system-scope fence); the host
         # polls the slot instead of recording an event per iteration -- no copy command and no barrier packet
         # between one iteration's last kernel and the next one's first (~15 us per iteration on a small shard)
-        err_host = torch.full((maxiter,), -1.0, dtype=torch.float64).pin_memory()
+        err_host = self._pinned_errors(maxiter)
         err_np = err_host.numpy()
         losses, converged = [], False
         cur, nxt = 0, 1
@@ -270,7 +287,7 @@ class ConjugateGrad:
 
         precond(r[0], z[0])
         p[0].copy_(z[0])
-        err_host = torch.full((maxiter, k), -1.0, dtype=torch.float64).pin_memory()
+        err_host = self._pinned_errors(maxiter, k)
         err_np = err_host.numpy()
         losses, converged = [], False
         cur, nxt = 0, 1
