@@ -326,7 +326,7 @@ def conv_featgen_probe(device, nseq=8192):
     """The convolution feature operator (cudaConv1dFGen's drop-in) at BASELINE configs[3]'s shape: one-hot protein-like
     sequences, L <= 512, 21 channels, conv_width 9, 16384 RFFs, 'sqrt' averaging; 8192 sequences per call (the window the
     feature cache is built in).  The kernel is vector-pipe bound: `priced` is count x measured issue cost of its k-mer
-    loop (profiles/r4_conv_inst_table.json, tools/count_loop_insts.py conv 8) over the measured time."""
+    loop (profiles/r5_conv_inst_table.json, tools/count_loop_insts.py conv 8) over the measured time."""
     import numpy as np
     import torch
     from xgpr_amd.kernels import make_kernel
@@ -352,11 +352,11 @@ def conv_featgen_probe(device, nseq=8192):
            "ms": ms, "sequences_per_s": nseq / (ms * 1e-3), "kmers": kmers, "tile_transforms_per_s": tiles / (ms * 1e-3),
            "note": "whole operator call (transform_x: scaling of the input copy, ordering kernel, feature kernel, float64 output)"}
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r4_conv_inst_table.json")))
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r5_conv_inst_table.json")))
         pipe_ms = tab["priced_vector_ns_per_tile_per_simd"] * tiles / 1024 * 1e-6
         out["vector_pipe"] = {"valu_insts_per_kmer_tile": tab["valu_instructions"],
                               "priced": {"pipe_ms": pipe_ms, "frac": pipe_ms / ms,
-                                         "source": "profiles/r4_conv_inst_table.json x profiles/r3_valu_cost.json (stored)"}}
+                                         "source": "profiles/r5_conv_inst_table.json x profiles/r3_valu_cost.json (stored)"}}
     except (OSError, KeyError, ValueError):
         pass
     return out
@@ -747,8 +747,8 @@ def main():
         kern.ztz_matvec_cached = origc
         cbytes = 4.0 * m * (hi - lo)
         ctraffic = None
-        try:   # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (profiles/r4_pmc_traffic_cached.json; stored)
-            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
+        try:   # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (profiles/r5_pmc_traffic_cached.json; stored)
+            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
         except (OSError, KeyError, ValueError):
             pass
         cached = {"ms_per_step": 1e3 * float(tc.item()) / args.steps, "cg_iters_per_sec": args.steps / float(tc.item()),
@@ -830,7 +830,7 @@ def main():
         # measured on, and labelled as such in the line
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")))
             c = pm["config"]
             if (c["rows_per_gpu"], c["dim"], c["rffs"]) == (n_local, d, m):
                 traffic = pm["hbm_bytes_per_launch"]
@@ -838,7 +838,7 @@ def main():
             pass
         # the resource this kernel is actually bound by: the vector pipe.  Three readings, each labelled:
         #  issue_slots -- vector instructions per wave tile (static count of the loop's hot path from the disassembly,
-        #                 tools/count_loop_insts.py -> profiles/r4_ztz3_inst_table.json) x tiles / live kernel time, against
+        #                 tools/count_loop_insts.py -> profiles/r5_ztz3_inst_table.json) x tiles / live kernel time, against
         #                 one wave-instruction per TWO cycles per SIMD at 2.4 GHz (the rate of v_add_f32; most of this
         #                 kernel's instructions -- packed, DPP, float64, conversions -- occupy the pipe for four cycles,
         #                 cos/sin for eight, so this reading cannot reach 1)
@@ -849,7 +849,7 @@ def main():
         #                 instruction stream, LDS traffic / barrier / prefetch compiled out), over the live kernel time
         vector_pipe = None
         try:
-            tab = json.load(open(os.path.join(ROOT, "profiles", "r4_ztz3_inst_table.json")))
+            tab = json.load(open(os.path.join(ROOT, "profiles", "r5_ztz3_inst_table.json")))
             if (d, m) == (1024, 8192):
                 tiles = n_local * ((m // 2 + 1023) // 1024)
                 peak_inst = 256 * 4 * 2.4e9 / 2
@@ -859,7 +859,7 @@ def main():
                                "issue_slots": {"achieved": inst_s / 1e9, "peak": peak_inst / 1e9, "unit": "G wave-instructions/s",
                                                "frac": inst_s / peak_inst},
                                "priced": {"pipe_ms": pipe_ms, "frac": pipe_ms / kern_ms,
-                                          "source": "profiles/r4_ztz3_inst_table.json x profiles/r3_valu_cost.json (stored)"},
+                                          "source": "profiles/r5_ztz3_inst_table.json x profiles/r3_valu_cost.json (stored)"},
                                "valu_only": valu_probe}
         except (OSError, KeyError, ValueError):
             pass
@@ -888,13 +888,13 @@ def main():
                        "rows_per_gpu": n_local, "lambda": 0.1, "sigma": 1.0},
             "roofline": {"kernel": "ztz3_kernel<10> (+ pack_radem, reduce_slabs)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r4_pmc_traffic.json (rocprofv3 --pmc passes of this "
+                         "traffic": traffic, "traffic_source": "profiles/r5_pmc_traffic.json (rocprofv3 --pmc passes of this "
                          "command; stored, not re-measured in this run)" if traffic is not None else None,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
                          "vector_pipe": vector_pipe,
                          "note": "HBM traffic of this kernel is only the X read; the binding resource is the vector pipe "
                                  "(butterflies, cos/sin, float64 dot + rank-1 update) at 3 waves/SIMD: vector_pipe, "
-                                 "profiles/r4_fused_pmc_sq.json, DESIGN.md section 3"},
+                                 "profiles/r5_fused_pmc_sq.json, DESIGN.md section 3"},
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},
