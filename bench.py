@@ -102,7 +102,7 @@ def direct_rccl_child(args, limit_s=None, cmd=None, side_file=None):
     rec = {"what": "bench.py --gpus %d with XGPR_RCCL_DIRECT=1, started after the main line was printed" % args.gpus,
            "status": None}
     try:
-        limit_s = float(os.environ.get("XGPR_BENCH_CHILD_TIMEOUT", "300")) if limit_s is None else float(limit_s)
+        limit_s = float(os.environ.get("XGPR_BENCH_CHILD_TIMEOUT", "180")) if limit_s is None else float(limit_s)
         if cmd is None:
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", "20", "--warmup", str(args.warmup),
                    "--rows", str(args.rows), "--dim", str(args.dim), "--rffs", str(args.rffs), "--rank-precond",
