@@ -118,6 +118,22 @@ def test_two_gloo_ranks_reach_the_loss_check_and_pass_it(tmp_path):
     assert abs(float(r0["loss"]) / expected - 1.0) < 1e-6
 
 
+def test_eight_gloo_ranks_solve_the_same_problem(tmp_path):
+    """The world size the driver's scaling run ends at: eight ranks (300 rows each, one thread each) reach and pass the loss
+    check; every rank holds the same replicated CG state; the loss is the one-rank value to the exchanged-sums tolerance."""
+    from xgpr_amd import dist as xd
+    expected = _solve(xd.Comm())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(8, port, str(tmp_path), expected), nprocs=8, join=True)
+    res = [np.load(tmp_path / f"loss_rank{r}.npz") for r in range(8)]
+    assert len({float(r["loss"]) for r in res}) == 1
+    assert all(bool(r["ok"]) and float(r["rtol"]) == 1e-5 for r in res)
+    # (eight partial sums per dot product instead of one: 1.9e-6 after 12 un-preconditioned iterations; two ranks: < 1e-6)
+    assert abs(float(res[0]["loss"]) / expected - 1.0) < 1e-5
+
+
 class _FakeRcclLib:
     """Stands in for libxgpr_hip.so's xgpr_rccl_* entry points: set-up succeeds everywhere except
     xgpr_rccl_comm_init on ``fail_rank``."""
