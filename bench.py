@@ -932,7 +932,13 @@ def main():
     if (args.gpus > 1 and comm.rank == 0 and not args.no_direct_child and "XGPR_BENCH_CHILD" not in os.environ
             and os.environ.get("XGPR_BENCH_DIRECT_CHILD", "1") != "0"):
         sys.stdout.flush()
-        direct_rccl_child(args)    # never raises, never touches stdout or the exit code
+        # this process still holds its GPU; the other ranks of this job are exiting.  Give them a moment (a GPU box admits only a few
+        # processes per device at once), and do not stack N more ranks on a device that all ranks share (one-device rehearsals)
+        if "XGPR_LOCAL_DEVICE" in os.environ and args.gpus > 3:
+            print("direct-rccl child: skipped (%d ranks share one device in this rehearsal)" % args.gpus, file=sys.stderr)
+        else:
+            time.sleep(float(os.environ.get("XGPR_BENCH_CHILD_DELAY", "3")))
+            direct_rccl_child(args)    # never raises, never touches stdout or the exit code
     if loss_check["ok"] is False:
         raise SystemExit(f"final loss {losses[-1]!r} differs from the stored {loss_check['expected']!r} (rtol {loss_check['rtol']}): "
                          "the timed iterations did not do the work they claim")
