@@ -247,7 +247,7 @@ def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_fa
     rng = np.random.default_rng(0)
     assert [ext.ztz_matvec_plan(d, f) for d, f in ((1024, 4096), (256, 2048), (256, 1024), (1024, 8192), (512, 5120),
                                                     (64, 2048), (20, 1024), (1022, 4096), (512, 16384), (2000, 4096))] == \
-        [1, 1, 2, 2, 2, 2, 2, 2, 3, 0]
+        [1, 1, 2, 3, 2, 2, 2, 2, 3, 0]
     monkeypatch.setattr(cgmod, "SMALL_SHARD_ROWS", 100)          # the 256-row shards below count as long ones
     pays = {}
     for d, m in ((256, 4096), (256, 2048), (1024, 16384), (64, 4096), (20, 2048), (254, 4096), (256, 32768)):
