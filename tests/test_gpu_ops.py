@@ -308,7 +308,11 @@ def test_error_behaviour(ext):
                                            (512, 32768, True, 700), (64, 20000, True, 333), (300, 18434, False, 65),
                                            # the two passes on the three-wave plan: tile groups of 2, 4 and 6, a ragged last tile
                                            (256, 18434, True, 130), (128, 22530, False, 90), (512, 26626, True, 77),
-                                           (1024, 24576, True, 50)])
+                                           (1024, 24576, True, 50),
+                                           # rows that are not whole aligned 16-byte groups (fetched float by float), five tiles per
+                                           # datapoint (ten of twelve waves), eight tiles (two passes), and the same beyond 8192 frequencies
+                                           (1022, 8192, True, 150), (130, 4096, False, 77), (513, 6144, True, 133), (250, 10240, True, 250),
+                                           (1000, 10000, False, 90), (1024, 16384, True, 140), (257, 16384, False, 60), (511, 20480, True, 70)])
 def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """hipZtZMatvec == Z.T @ (Z @ v) with Z = transform_x(x) from the oracle (incl. Z[:,0] = 1);
     f64 accumulation, so 1e-9 relative in the max norm; and bit-reproducible run to run."""
@@ -340,6 +344,19 @@ def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     ext.hipZtY(dev(x), dev(radem), dev(chi), dev(y), zty, icpt)
     refy = z.T @ y
     assert np.abs(zty.cpu().numpy() - refy).max() <= 1e-6 * np.abs(refy).max()
+    # a base pointer off the 16-byte boundary (a view one float into a buffer): same numbers as the aligned copy
+    if rffs % 4 == 0 and d <= 1024:
+        buf = torch.empty(n * d + 1, dtype=torch.float32, device=DEV)
+        xo = buf[1:].view(n, d)
+        xo.copy_(dev(x))
+        assert xo.data_ptr() % 16 != 0
+        out5 = torch.zeros_like(out)
+        ext.hipZtZMatvec(xo, dev(radem), dev(chi), dev(v), out5, icpt)
+        assert np.abs(out5.cpu().numpy() - ref).max() <= 1e-6 * np.abs(ref).max()
+        zc, zo = (torch.empty((n, rffs), dtype=torch.float32, device=DEV) for _ in range(2))
+        ext.hipRBFFeatureCache(dev(x), zc, dev(radem), dev(chi))
+        ext.hipRBFFeatureCache(xo, zo, dev(radem), dev(chi))
+        assert torch.equal(zc, zo)
 
 
 @pytest.mark.parametrize("d,rffs,icpt,n", [(32, 512, True, 2000), (20, 64, False, 100), (256, 4096, True, 3000),

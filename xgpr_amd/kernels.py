@@ -174,8 +174,9 @@ class SORFKernel(KernelBase):
         predicate (xgpr_ztz_matvec_plan).  On the three-wave single-pass kernel regenerating a 1024-frequency tile takes
         ~1.30 ns (cfg3: 5.19 ms per 1e6 rows) while the cache streams it in ~1.33 ns (32.8 GB at 6.2 TB/s: 5.32 ms) --
         regenerating wins or ties (cfg2: 0.32 / 0.33 ms) and leaves the HBM free.  Every other plan loses to the stream:
-        the two-wave kernel (one tile per datapoint, 5 / 7 / 8 tiles, padded width < 128, d % 4 != 0) and the two feature
-        passes past 8192 frequencies (cfg5's share: 9.1 / 6.1 ms).  bench.py reports both modes (`cached_z_mode`)."""
+        the two-wave kernel (one tile per datapoint, 7 tiles, padded width < 128) and the two feature
+        passes (eight tiles per datapoint, or more than 8192 frequencies; cfg5's share: 9.1 / 6.1 ms).  bench.py reports both
+        modes (`cached_z_mode`)."""
         return ext.ztz_matvec_plan(self._xdim[-1], self.num_freqs) != 1
 
     def build_feature_cache(self, dataset):
