@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # register-limited waves per SIMD the design relies on: the fused matvec, the convolution feature
 # operator and the feature operator run three / three / six waves per SIMD
-HOT = {"ztz3_kernel<10, 0>": 3, "ztz3_kernel<8, 0>": 3, "ztz3_kernel<10, 1>": 3, "wave_conv_kernel<8, 0>": 3,
+HOT = {"ztz3_kernel<10, 0, false>": 3, "ztz3_kernel<8, 0, false>": 3, "ztz3_kernel<10, 1, false>": 3, "ztz3_kernel<10, 0, true>": 3, "wave_conv_kernel<8, 0>": 3,
        "wave_conv_kernel<10, 0>": 3, "wave_rbf_kernel<10, 0>": 6}
 
 

@@ -18,7 +18,7 @@ with tempfile.TemporaryDirectory() as td:
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-S", "--cuda-device-only",
                     os.path.join(ROOT, "xgpr_amd/csrc/xgpr_hip.hip"), "-o", asm], check=True, capture_output=True)
     lines = open(asm).read().split("\n")
-name = f"ztz3_kernelILi{lg}ELi0E" if which == "ztz3" else f"wave_conv_kernelILi{lg}ELi0E"      # MODE 0 = Z3_MATVEC / CONV_FGEN
+name = f"ztz3_kernelILi{lg}ELi0ELb0EE" if which == "ztz3" else f"wave_conv_kernelILi{lg}ELi0E"      # MODE 0 = Z3_MATVEC / CONV_FGEN
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and name in l and ":" in l.split(";")[0])
 end = next(i for i in range(start, len(lines)) if ".amdhsa_kernel" in lines[i])
 body = lines[start:end]

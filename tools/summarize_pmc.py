@@ -19,7 +19,7 @@ def one(pattern):
 
 
 shutil.copy(one("prof_stats/*/*kernel_stats.csv"), os.path.join(P, f"{ROUND}_bench_n1_kernel_stats.csv"))
-KERNELS = {"ztz3_kernel<10, 0>": "fused", "ztz3_kernel<10, 5>": "cache_rows_z3", "sketch_gemm_lds_kernel<": "sketch_gemm", "srht_sample_rows": "srht_rows", "zcache_ztz_kernel": "cached", "zblock_t_kernel": "block_t", "zblock_w_kernel": "block_w",
+KERNELS = {"ztz3_kernel<10, 0": "fused", "ztz3_kernel<10, 5": "cache_rows_z3", "sketch_gemm_lds_kernel<": "sketch_gemm", "srht_sample_rows": "srht_rows", "zcache_ztz_kernel": "cached", "zblock_t_kernel": "block_t", "zblock_w_kernel": "block_w",
            "reduce_slabs_kernel": "reduce", "wave_rbf_kernel": "featgen"}
 per = {}
 for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
