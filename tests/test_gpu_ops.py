@@ -312,7 +312,10 @@ def test_error_behaviour(ext):
                                            # rows that are not whole aligned 16-byte groups (fetched float by float), five tiles per
                                            # datapoint (ten of twelve waves), eight tiles (two passes), and the same beyond 8192 frequencies
                                            (1022, 8192, True, 150), (130, 4096, False, 77), (513, 6144, True, 133), (250, 10240, True, 250),
-                                           (1000, 10000, False, 90), (1024, 16384, True, 140), (257, 16384, False, 60), (511, 20480, True, 70)])
+                                           (1000, 10000, False, 90), (1024, 16384, True, 140), (257, 16384, False, 60), (511, 20480, True, 70),
+                                           # 16 <= padded width < 128 on the three-wave kernel (two or more tiles per datapoint)
+                                           (32, 4096, True, 300), (64, 8192, False, 200), (20, 6144, True, 150), (16, 4096, False, 170),
+                                           (9, 10240, True, 120), (50, 4096, False, 130), (33, 6000, True, 90), (64, 16384, True, 80)])
 def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """hipZtZMatvec == Z.T @ (Z @ v) with Z = transform_x(x) from the oracle (incl. Z[:,0] = 1);
     f64 accumulation, so 1e-9 relative in the max norm; and bit-reproducible run to run."""
