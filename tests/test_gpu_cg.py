@@ -237,7 +237,7 @@ def test_batched_rhs_cg_matches_oracle(oracle):
 def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_faster(monkeypatch):
     """cache_features="auto" follows the matvec launcher's own plan (xgpr_ztz_matvec_plan): one right-hand side on the
     single-pass three-wave kernel regenerates (a long shard: at least as fast as the HBM stream of the cache); every
-    other plan -- the two-wave kernel (one tile per datapoint, 7 tiles, padded width < 16), two feature
+    other plan -- the two-wave kernel (one tile per datapoint, 7 tiles, no other shape), two feature
     passes (num_freqs > 8192, or eight tiles per datapoint) --, a short shard, a block of right-hand sides or a convolution kernel keep the float32
     features resident (when they fit).  Measured: tools/cache_rule_probe.py."""
     from xgpr_amd.kernels import make_kernel

@@ -315,7 +315,10 @@ def test_error_behaviour(ext):
                                            (1000, 10000, False, 90), (1024, 16384, True, 140), (257, 16384, False, 60), (511, 20480, True, 70),
                                            # 16 <= padded width < 128 on the three-wave kernel (two or more tiles per datapoint)
                                            (32, 4096, True, 300), (64, 8192, False, 200), (20, 6144, True, 150), (16, 4096, False, 170),
-                                           (9, 10240, True, 120), (50, 4096, False, 130), (33, 6000, True, 90), (64, 16384, True, 80)])
+                                           (9, 10240, True, 120), (50, 4096, False, 130), (33, 6000, True, 90), (64, 16384, True, 80),
+                                           # padded width <= 16: the tile never leaves the rows layout (no exchange); rows shorter than 16 floats
+                                           (2, 4096, True, 210), (3, 6144, False, 100), (5, 4096, True, 160), (8, 8192, False, 140),
+                                           (12, 4096, True, 110), (7, 10240, False, 75), (4, 2050, True, 65), (16, 12288, True, 55)])
 def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """hipZtZMatvec == Z.T @ (Z @ v) with Z = transform_x(x) from the oracle (incl. Z[:,0] = 1);
     f64 accumulation, so 1e-9 relative in the max norm; and bit-reproducible run to run."""
