@@ -20,7 +20,7 @@ for n in 2 4; do
   python3 -c "
 import json
 d=json.loads(open('gpurun_out/r5/bench_gloo_n$n.json').read().strip().splitlines()[-1])
-c=json.load(open('gpurun_out/r5/bench_gloo_n${n}_child.json'))
+import os; c=json.load(open('gpurun_out/r5/bench_gloo_n${n}_child.json')) if os.path.exists('gpurun_out/r5/bench_gloo_n${n}_child.json') else {'status': 'skipped (ranks share one device)'}
 print('N=$n (gloo, one device) ms/step %.3f loss %r check %s tol %s ranks %s | child: %s, loss check %s' % (d['ms_per_step'], d['final_loss'], d['final_loss_check'], d['fit_to_tol']['iterations'], d['distributed']['n_ranks_seen'], c['status'], (c.get('line') or {}).get('final_loss_check')))
 "
 done
