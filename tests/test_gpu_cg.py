@@ -237,7 +237,7 @@ def test_batched_rhs_cg_matches_oracle(oracle):
 def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_faster(monkeypatch):
     """cache_features="auto" follows the matvec launcher's own plan (xgpr_ztz_matvec_plan): one right-hand side on the
     single-pass three-wave kernel regenerates (a long shard: at least as fast as the HBM stream of the cache); every
-    other plan -- the two-wave kernel (one tile per datapoint, 7 tiles, no other shape), two feature
+    other plan -- the two-wave kernel (one tile per datapoint at padded width >= 128, seven tiles), two feature
     passes (num_freqs > 8192, or eight tiles per datapoint) --, a short shard, a block of right-hand sides or a convolution kernel keep the float32
     features resident (when they fit).  Measured: tools/cache_rule_probe.py."""
     from xgpr_amd.kernels import make_kernel
@@ -247,7 +247,7 @@ def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_fa
     rng = np.random.default_rng(0)
     assert [ext.ztz_matvec_plan(d, f) for d, f in ((1024, 4096), (256, 2048), (256, 1024), (1024, 8192), (512, 5120),
                                                     (64, 2048), (20, 1024), (1022, 4096), (512, 16384), (2000, 4096))] == \
-        [1, 1, 2, 3, 1, 1, 2, 1, 3, 0]
+        [1, 1, 2, 3, 1, 1, 1, 1, 3, 0]
     monkeypatch.setattr(cgmod, "SMALL_SHARD_ROWS", 100)          # the 256-row shards below count as long ones
     pays = {}
     for d, m in ((256, 4096), (256, 2048), (1024, 16384), (64, 4096), (20, 2048), (254, 4096), (256, 32768)):
@@ -260,7 +260,7 @@ def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_fa
         assert _resolve_cache_mode("auto", k, ds) is k.cache_pays()
         assert _resolve_cache_mode("auto", k, ds, block=True) is True
         assert _resolve_cache_mode(True, k, ds) is True and _resolve_cache_mode(False, k, ds) is False
-    assert pays == {(256, 4096): False, (256, 2048): True, (1024, 16384): True, (64, 4096): False, (20, 2048): True,
+    assert pays == {(256, 4096): False, (256, 2048): True, (1024, 16384): True, (64, 4096): False, (20, 2048): False,
                     (254, 4096): False, (256, 32768): True}
     monkeypatch.setattr(cgmod, "SMALL_SHARD_ROWS", 200_000)      # ... and as short ones: the stream's smaller cost per launch wins
     x = rng.standard_normal((256, 256)).astype(np.float32)

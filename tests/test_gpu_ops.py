@@ -320,7 +320,9 @@ def test_error_behaviour(ext):
                                            (2, 4096, True, 210), (3, 6144, False, 100), (5, 4096, True, 160), (8, 8192, False, 140),
                                            (12, 4096, True, 110), (7, 10240, False, 75), (4, 2050, True, 65), (16, 12288, True, 55),
                                            # ... and the two passes beyond 8192 frequencies at those widths
-                                           (32, 32768, True, 90), (64, 18434, False, 70), (8, 20480, True, 60), (50, 16384, True, 100)])
+                                           (32, 32768, True, 90), (64, 18434, False, 70), (8, 20480, True, 60), (50, 16384, True, 100),
+                                           # one tile per datapoint below padded width 128 (twelve one-wave slots)
+                                           (32, 2048, True, 400), (64, 1024, False, 333), (10, 512, True, 257), (3, 1500, False, 129)])
 def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """hipZtZMatvec == Z.T @ (Z @ v) with Z = transform_x(x) from the oracle (incl. Z[:,0] = 1);
     f64 accumulation, so 1e-9 relative in the max norm; and bit-reproducible run to run."""
