@@ -167,7 +167,7 @@ size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2);
 /* Which plan xgpr_ztz_matvec_f32 runs for rows of d floats (16-byte aligned) and num_freqs frequencies -- what a caller
  * that can also keep the features resident (xgpr_rbf_feature_cache_f32 + xgpr_zcache_matvec_f32) decides by:
  * 1 = one pass, three waves per SIMD (regenerating is as fast as streaming the cache); 2 = one pass, two-wave kernel
- * (one or seven tiles per datapoint, or padded width < 128: slower than the cache stream); 3 = two feature passes (num_freqs > 8192, or eight tiles per datapoint: 7168 < num_freqs <= 8192);
+ * (seven tiles per datapoint, or one tile at padded width >= 128: slower than the cache stream); 3 = two feature passes (num_freqs > 8192, or eight tiles per datapoint: 7168 < num_freqs <= 8192);
  * 0 = unsupported shape. */
 int xgpr_ztz_matvec_plan(long d, long num_freqs);
 int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v,

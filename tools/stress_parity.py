@@ -28,8 +28,9 @@ def T(a):
 
 
 for case in range(cases):
-    d = int(rng.choice([3, 20, 32, 100, 128, 256, 300, 512, 700, 1024]))
-    rffs = int(rng.choice([64, 512, 2048, 3000, 4096, 6144, 8192, 12288, 16384])) // 2 * 2
+    # (round 5: row lengths that are not multiples of 4, every padded width from 2 up, 5 / 7 / 8 tiles per datapoint)
+    d = int(rng.choice([2, 3, 7, 16, 20, 32, 33, 64, 100, 128, 130, 256, 300, 512, 617, 700, 1023, 1024]))
+    rffs = int(rng.choice([64, 512, 2048, 3000, 4096, 6144, 8192, 10000, 12288, 14000, 16384])) // 2 * 2
     n = int(rng.integers(1, 700))
     if case % 4 == 3 and rffs <= 4096:
         n = int(rng.integers(20000, 60000))      # a launch that fills the chip: loads and stores in flight everywhere
