@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (rows, d, num_rffs): whole tiles, a ragged last tile, tile counts that do not divide 12 (5, 7: tile groups with idle
 # waves), more than 8 tiles (groups on blockIdx.y), one row, fewer rows than slots, every padded width 128 .. 1024
 SHAPES = [(700, 1024, 8192), (513, 256, 4096), (37, 128, 2048 + 2 * 300), (1, 512, 4096), (260, 300, 2 * 5000),
-          (129, 700, 2 * 7168), (65, 512, 32768), (9, 1000, 2 * 9000), (300, 132, 6144)]
+          (129, 700, 2 * 7168), (65, 512, 32768), (9, 1000, 2 * 9000), (300, 132, 6144),
+          # padded widths 32 and 64 on the three-wave plan (round 5), rows that are not multiples of four floats
+          (400, 64, 8192), (333, 32, 4096), (150, 50, 2 * 5000), (77, 33, 6144), (210, 1022, 8192)]
 
 CHILD = r"""
 import sys, numpy as np, torch
