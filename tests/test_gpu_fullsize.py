@@ -14,7 +14,11 @@ DEV = "cuda"
 def _cfg(name):
     return {"cfg2": ("RBF", 100_000, 256, 4096, {}),
             "cfg3": ("Matern", 1_000_000, 1024, 8192, {"matern_nu": 5 / 2}),
-            "cfg5": ("RBF", 2_000_000, 512, 32768, {})}[name]
+            "cfg5": ("RBF", 2_000_000, 512, 32768, {}),
+            # the shapes the three-wave kernel took over in round 5: tabular widths (rows-only and transposed-columns layouts), a row
+            # length that is not a multiple of four floats, five tiles per datapoint, eight tiles (two passes)
+            "tab16": ("RBF", 300_000, 16, 8192, {}), "tab50": ("Matern", 300_000, 50, 4096, {"matern_nu": 5 / 2}),
+            "odd617": ("RBF", 200_000, 617, 10_000, {}), "m16384": ("RBF", 150_000, 1000, 16384, {})}[name]
 
 
 def _data(n, d, seed=0):
@@ -56,7 +60,8 @@ def test_feature_rows_have_unit_norm(cfg):
     assert worst < 2e-6, worst
 
 
-@pytest.mark.parametrize("cfg,rows", [("cfg2", 100_000), ("cfg3", 131_072), ("cfg5", 70_000)])
+@pytest.mark.parametrize("cfg,rows", [("cfg2", 100_000), ("cfg3", 131_072), ("cfg5", 70_000), ("tab16", 300_000), ("tab50", 300_000),
+                                      ("odd617", 200_000), ("m16384", 150_000)])
 def test_fused_matvec_equals_chunked_path(cfg, rows):
     """Fused Z^T(Zv) == sum over chunks of Z.T @ (Z @ v) with Z from the stand-alone operator and
     the library GEMV (an independent code path), and is linear and symmetric."""
