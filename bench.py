@@ -882,6 +882,12 @@ def main():
             "dtype": "f32 (SORF + cos/sin) / f64 (Z^T Z p accumulation and CG state)",
             "data": "synthetic",
             "build_id": build_id,
+            "direct_rccl_child": (None if args.gpus == 1 else
+                                  "after this line rank 0 starts a fresh `bench.py --gpus %d` with XGPR_RCCL_DIRECT=1 under a watchdog; its record "
+                                  "(direct_equals_torch_allreduce, final_loss_check, all-reduce times) goes to stderr and "
+                                  "gpurun_out/bench_direct_rccl_child.json and cannot change this line or the exit code" % args.gpus
+                                  if (not args.no_direct_child and "XGPR_BENCH_CHILD" not in os.environ
+                                      and os.environ.get("XGPR_BENCH_DIRECT_CHILD", "1") != "0") else "off"),
             "config": {"workload": "BASELINE configs[2]: Matern-5/2, N=%d, d=%d, %d RFFs, rows sharded over %d GPU(s), "
                                    "rank-%d SRHT preconditioner (all rows), CG step" %
                                    (n, d, m, args.gpus, args.rank_precond),
