@@ -232,11 +232,11 @@ def test_cfg3_full_size_matvec_is_the_sum_of_its_shards_and_reproducible():
     assert float((zty - zty_parts).abs().max() / zty.abs().max()) < 1e-12
 
 
-def test_two_pass_matvec_across_row_windows_is_additive():
+@pytest.mark.parametrize("n,d,m", [(150_000, 128, 18_434), (150_000, 32, 32_768), (140_000, 13, 16_384), (135_000, 1000, 16_384)])
+def test_two_pass_matvec_across_row_windows_is_additive(n, d, m):
     """More than 8192 frequencies: the matvec runs as a dot pass + an update pass per window of 131 072 rows, slabs
     accumulating over windows.  A launch that spans two windows equals the sum of the two parts, and is reproducible."""
     from xgpr_amd.kernels import make_kernel
-    n, d, m = 150_000, 128, 18_434
     k = make_kernel("RBF", (n, d), m, 123, DEV, {})
     k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
     x = _data(n, d, seed=5)
