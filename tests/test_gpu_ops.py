@@ -126,7 +126,14 @@ def test_g2_rbf_golden(ext):
     (50, 128, False, 11), (64, 2048, True, 9), (100, 300, False, 13), (128, 4096, True, 7),
     (256, 4096, True, 300), (300, 1000, False, 6), (512, 16384, False, 3), (513, 4096, True, 5),
     (1000, 8192, True, 4), (1024, 8192, True, 64), (1024, 2050, False, 3), (1025, 4096, True, 3),
-    (2003, 4000, False, 3)])
+    (2003, 4000, False, 3),
+    # padded widths 2048 / 4096: transforms of two / four wave tiles (cross-wave stages); the reference's own test shapes
+    # (tests/fht_operations_tests/test_rbf_rfgen.py:37,41) among them; ragged last tiles, tile groups, rows off the 16-byte grid
+    (1076, 8192, True, 40), (2003, 4000, True, 70), (2048, 8192, False, 33), (1025, 2048, True, 9), (1500, 1000, False, 21),
+    (2000, 16384, True, 25), (1999, 12290, False, 14), (4000, 8192, True, 30), (4096, 4096, False, 19), (3001, 16384, True, 11),
+    (2500, 2, False, 5), (4096, 20482, True, 7),
+    # beyond 4096: the any-width LDS path
+    (5000, 8192, True, 3), (8192, 16384, False, 2)])
 def test_rbf_vs_oracle(ext, oracle, d, rffs, icpt, n):
     from oracle import oracle as orc
     rng = np.random.default_rng(d * 7 + rffs)
@@ -142,8 +149,11 @@ def test_rbf_vs_oracle(ext, oracle, d, rffs, icpt, n):
 
 @pytest.mark.parametrize("d,rffs,amp", [(50, 128, 3e4), (1024, 8192, 2e4), (256, 4096, 5e4), (20, 64, 1e6), (512, 2048, 3e9),
                                         (512, 2048, 1e15), (1024, 8192, 1e24), (40, 256, 1e28),
-                                        # generic-width operator (padded width 2048: generic_sorf_kernel, Cephes kernels)
-                                        (1500, 4096, 1e5), (1500, 4096, 1e22)])
+                                        # padded widths 2048 / 4096 (wide transforms: the argument is still bit-identical)
+                                        (1500, 4096, 1e5), (1500, 4096, 1e22), (2003, 4000, 3e4), (4000, 8192, 1e5), (3000, 2048, 1e9),
+                                        (2048, 16384, 1e4),
+                                        # any-width LDS path (padded width 8192: generic_sorf_kernel, Cephes kernels)
+                                        (5000, 4096, 1e5), (5000, 4096, 1e22)])
 def test_large_arguments_take_the_rare_path(ext, oracle, d, rffs, amp):
     """Un-normalised inputs: cos/sin arguments at and beyond 2^18 take the kernels' rare branch (common.inc turns_fixed:
     the angle in revolutions from the float's integer significand and a table of frac(2^k / (2 pi))), good for EVERY
@@ -178,8 +188,8 @@ def test_large_arguments_take_the_rare_path(ext, oracle, d, rffs, amp):
     assert np.isnan(got[~finite]).all() and np.isfinite(got[finite]).all()
     err = np.abs(got - ref)[finite].max()
     assert err <= 4e-7 * scale, f"max abs err {err:.3e} vs {4e-7 * scale:.3e}"
-    if d > 1024:
-        return                                      # the cache build and the fused matvec serve padded widths <= 1024
+    if d > 4096:
+        return                                      # the cache build and the fused matvec serve padded widths <= 4096
     zc = torch.empty((n, rffs), dtype=torch.float32, device=DEV)
     ext.hipRBFFeatureCache(dev(x), zc, dev(radem), dev(chi))
     same = zc.double().cpu().numpy() * float(np.float32(scale))
@@ -322,7 +332,13 @@ def test_error_behaviour(ext):
                                            # ... and the two passes beyond 8192 frequencies at those widths
                                            (32, 32768, True, 90), (64, 18434, False, 70), (8, 20480, True, 60), (50, 16384, True, 100),
                                            # one tile per datapoint below padded width 128 (twelve one-wave slots)
-                                           (32, 2048, True, 400), (64, 1024, False, 333), (10, 512, True, 257), (3, 1500, False, 129)])
+                                           (32, 2048, True, 400), (64, 1024, False, 333), (10, 512, True, 257), (3, 1500, False, 129),
+                                           # padded widths 2048 / 4096: two / four wave tiles per transform, one cross-wave exchange per round;
+                                           # two and four computed tiles, ragged ones, the two passes in groups of 2 / 4, rows off the 16-byte grid
+                                           (1076, 8192, True, 300), (2003, 4000, False, 250), (2048, 8192, True, 200), (1025, 2048, False, 150),
+                                           (1500, 6146, True, 170), (2000, 12288, False, 120), (2047, 16384, True, 90), (1030, 20482, False, 60),
+                                           (4000, 8192, True, 160), (4096, 4096, False, 140), (2049, 2048, True, 100), (3000, 6000, False, 80),
+                                           (4000, 16384, True, 70), (3333, 24578, False, 40), (2050, 50, True, 30)])
 def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """hipZtZMatvec == Z.T @ (Z @ v) with Z = transform_x(x) from the oracle (incl. Z[:,0] = 1);
     f64 accumulation, so 1e-9 relative in the max norm; and bit-reproducible run to run."""
@@ -355,7 +371,7 @@ def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
     refy = z.T @ y
     assert np.abs(zty.cpu().numpy() - refy).max() <= 1e-6 * np.abs(refy).max()
     # a base pointer off the 16-byte boundary (a view one float into a buffer): same numbers as the aligned copy
-    if rffs % 4 == 0 and d <= 1024:
+    if rffs % 4 == 0 and d <= 4096:
         buf = torch.empty(n * d + 1, dtype=torch.float32, device=DEV)
         xo = buf[1:].view(n, d)
         xo.copy_(dev(x))
@@ -373,7 +389,10 @@ def test_fused_matvec_vs_oracle(ext, oracle, d, rffs, icpt, n):
                                            (100, 3000, True, 777), (1024, 8192, True, 1500), (512, 16384, False, 300),
                                            (7, 10, True, 33), (64, 6146, True, 5), (3, 2, False, 1),
                                            (512, 32768, True, 300), (256, 20002, False, 77), (64, 16386, True, 40),
-                                           (1024, 32768, False, 3), (128, 24580, True, 1)])
+                                           (1024, 32768, False, 3), (128, 24580, True, 1),
+                                           # padded widths 2048 / 4096
+                                           (1076, 8192, True, 200), (2003, 4000, False, 50), (4000, 8192, True, 90), (2500, 12290, False, 20),
+                                           (1100, 2, True, 4), (3000, 32768, True, 6)])
 def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
     """The resident float32 feature cache holds exactly the float32 cos/sin the float64 operator
     widens (bit-for-bit: cache * scale == hipRBFFeatureGen output), and the matvec streamed from it

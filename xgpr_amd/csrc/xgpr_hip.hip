@@ -198,8 +198,9 @@ size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2) {
 }
 int xgpr_ztz_matvec_plan(long d, long num_freqs) {
     const long P = padded_width(d);
-    if (P > 1024 || num_freqs < 1 || num_freqs > 65536) return 0;
+    if (P > 4096 || num_freqs < 1 || num_freqs > 65536) return 0;
     if (ztz_takes_two_passes(d, P, num_freqs, true)) return 3;
+    if (P > 1024) return ztz3_shape_ok(d, P, ztz3_compute_tiles(P, num_freqs)) ? 1 : 0;
     return ztz3_shape_ok(d, P, (int)((num_freqs + 1023) / 1024)) ? 1 : 2;
 }
 int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v, double *w_out,

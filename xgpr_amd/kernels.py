@@ -174,10 +174,11 @@ class SORFKernel(KernelBase):
         predicate (xgpr_ztz_matvec_plan).  On the three-wave single-pass kernel regenerating a 1024-frequency tile takes
         ~1.30 ns (cfg3: 5.19 ms per 1e6 rows) while the cache streams it in ~1.33 ns (32.8 GB at 6.2 TB/s: 5.32 ms) --
         regenerating wins or ties (cfg2: 0.32 / 0.33 ms) and leaves the HBM free.  Every other plan loses to the stream:
-        the two-wave kernel (one tile per datapoint, 7 tiles, padded width < 128) and the two feature
-        passes (eight tiles per datapoint, or more than 8192 frequencies; cfg5's share: 9.1 / 6.1 ms).  bench.py reports both
-        modes (`cached_z_mode`)."""
-        return ext.ztz_matvec_plan(self._xdim[-1], self.num_freqs) != 1
+        the two-wave kernel (one tile per datapoint at padded width >= 128, seven tiles), the two feature passes (eight
+        tiles per datapoint, or more than 8192 frequencies; cfg5's share: 9.1 / 6.1 ms) and the wide transforms of padded
+        width 2048 / 4096 (cross-wave stages: slower per tile than the stream).  bench.py reports both modes
+        (`cached_z_mode`)."""
+        return ext.ztz_matvec_plan(self._xdim[-1], self.num_freqs) != 1 or padded_dims(self._xdim[-1]) > 1024
 
     def build_feature_cache(self, dataset):
         x_scaled = dataset.scaled_x(self.hyperparams[1])
@@ -197,7 +198,7 @@ class SORFKernel(KernelBase):
     # ---- block of right-hand sides (approximate-NMLL probes, k = 26): float64 matrix cores over
     # the float32 cache, either the resident one or a window of rows regenerated into scratch
     def block_ok(self):
-        return padded_dims(self._xdim[-1]) <= 1024 and self.num_rffs % 4 == 0
+        return padded_dims(self._xdim[-1]) <= FUSED_MAX_WIDTH and self.num_rffs % 4 == 0
 
     def fill_feature_cache(self, x_scaled, zcache):
         ext.hipRBFFeatureCache(x_scaled, zcache, self.radem_diag, self.chi_arr)
@@ -222,13 +223,15 @@ class SORFKernel(KernelBase):
         return z
 
     def fused_ok(self):
-        """The fused kernels cover padded width <= 1024 (single pass up to num_freqs = 8192, the
-        two-pass form beyond, up to 65536)."""
-        return padded_dims(self._xdim[-1]) <= 1024 and self.num_freqs <= 65536
+        """The fused kernels cover padded width <= 4096 (single pass up to num_freqs = 7168 -- 4096 at padded widths
+        2048 / 4096, whose transforms span two / four wave tiles --, the two-pass form beyond, up to 65536)."""
+        return padded_dims(self._xdim[-1]) <= FUSED_MAX_WIDTH and self.num_freqs <= 65536
 
     def workspace_bytes(self):
         return ext.ztz_workspace_bytes(self.num_rffs, self.radem_diag.shape[2])
 
+
+FUSED_MAX_WIDTH = 4096   # padded input width the wave-tile kernels serve (include/xgpr_hip.h); beyond it: the any-width LDS path
 
 BLOCK_COLS = 32          # right-hand sides per call of the block matvec (include/xgpr_hip.h)
 
