@@ -246,11 +246,12 @@ def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_fa
     from xgpr_amd.cg import _resolve_cache_mode
     rng = np.random.default_rng(0)
     assert [ext.ztz_matvec_plan(d, f) for d, f in ((1024, 4096), (256, 2048), (256, 1024), (1024, 8192), (512, 5120),
-                                                    (64, 2048), (20, 1024), (1022, 4096), (512, 16384), (2000, 4096))] == \
-        [1, 1, 2, 3, 1, 1, 1, 1, 3, 0]
+                                                    (64, 2048), (20, 1024), (1022, 4096), (512, 16384), (2000, 4096),
+                                                    (2000, 2000), (1025, 100), (4000, 4096), (2000, 4097), (4000, 8192), (5000, 4096))] == \
+        [1, 1, 2, 3, 1, 1, 1, 1, 3, 1, 1, 1, 1, 3, 3, 0]
     monkeypatch.setattr(cgmod, "SMALL_SHARD_ROWS", 100)          # the 256-row shards below count as long ones
     pays = {}
-    for d, m in ((256, 4096), (256, 2048), (1024, 16384), (64, 4096), (20, 2048), (254, 4096), (256, 32768)):
+    for d, m in ((256, 4096), (256, 2048), (1024, 16384), (64, 4096), (20, 2048), (254, 4096), (256, 32768), (2003, 4000), (4000, 8192)):
         x = rng.standard_normal((256, d)).astype(np.float32)
         ds = build_regression_dataset(x, rng.standard_normal(256), chunk_size=128, device=DEV)
         k = make_kernel("RBF", x.shape, m, 123, DEV, {})
@@ -261,7 +262,9 @@ def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_fa
         assert _resolve_cache_mode("auto", k, ds, block=True) is True
         assert _resolve_cache_mode(True, k, ds) is True and _resolve_cache_mode(False, k, ds) is False
     assert pays == {(256, 4096): False, (256, 2048): True, (1024, 16384): True, (64, 4096): False, (20, 2048): False,
-                    (254, 4096): False, (256, 32768): True}
+                    (254, 4096): False, (256, 32768): True,
+                    # padded widths 2048 / 4096 (wide transforms: 1.8-2.4 ns per tile regenerated against 1.33 streamed)
+                    (2003, 4000): True, (4000, 8192): True}
     monkeypatch.setattr(cgmod, "SMALL_SHARD_ROWS", 200_000)      # ... and as short ones: the stream's smaller cost per launch wins
     x = rng.standard_normal((256, 256)).astype(np.float32)
     ds = build_regression_dataset(x, rng.standard_normal(256), chunk_size=128, device=DEV)
