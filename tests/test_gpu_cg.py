@@ -271,6 +271,12 @@ def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_fa
     k = make_kernel("RBF", x.shape, 4096, 123, DEV, {})
     k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
     assert not k.cache_pays() and _resolve_cache_mode("auto", k, ds) is True
+    # ... but not below padded width 128, where regenerating wins on short shards too (profiles/r6_cache_rule_125k.json)
+    x = rng.standard_normal((256, 64)).astype(np.float32)
+    ds = build_regression_dataset(x, rng.standard_normal(256), chunk_size=128, device=DEV)
+    k = make_kernel("RBF", x.shape, 8192, 123, DEV, {})
+    k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+    assert not k.cache_pays() and _resolve_cache_mode("auto", k, ds) is False
 
 
 def test_cg_with_resident_feature_cache_matches_regenerating_cg():

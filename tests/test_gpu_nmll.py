@@ -217,6 +217,40 @@ def test_g15_crude_tuning_vs_reference():
     assert np.abs(hp - g["crude_hparams"]).max() < 0.2
 
 
+def test_windowed_block_matvec_with_a_ragged_last_window(monkeypatch):
+    """A block of right-hand sides without a resident cache, over more rows than one window of regenerated feature rows: the
+    last, shorter window needs a LARGER workspace than a full one (the split projection's partials are reserved for short
+    launches only: xgpr_zcache_block_workspace_bytes(65536, ., 8) < (33920, ., 8)), which the round-5 tree sized once per solve.
+    Windows of 65536 rows over 65536 + 33920 rows, against the same product on one window."""
+    from xgpr_amd.kernels import make_kernel, block_workspace_bytes
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import ConjugateGrad
+    n, d, m, k = 65536 + 33920, 24, 2048, 8
+    assert block_workspace_bytes(33920, m, k) > block_workspace_bytes(65536, m, k), "the case must be the non-monotone one"
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, d, device=DEV, generator=g) / d ** 0.5
+    y = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    ds = build_regression_dataset(x, y, chunk_size=16384, device=DEV)
+    kern = make_kernel("RBF", (n, d), m, 123, DEV, {})
+    kern.set_hyperparams(np.array([0.5, 1.0]), logspace=False)
+    vec = torch.randn(m, k, dtype=torch.float64, device=DEV, generator=g)
+    outs = []
+    for wbytes in (65536 * 4 * m, 8 << 30):
+        monkeypatch.setattr(ConjugateGrad, "BLOCK_WINDOW_BYTES", wbytes)
+        cg = ConjugateGrad(cache_features=False)
+        out = torch.zeros_like(vec)
+        cg._matvec(ds, kern, vec, out, add_ridge=False)
+        outs.append(out)
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-10 * float(outs[1].abs().max())
+    z = kern.transform_x(x[:4096])
+    ref_part = z.T @ (z @ vec)            # sanity on a slice: same operator
+    cg = ConjugateGrad(cache_features=False)
+    ds2 = build_regression_dataset(x[:4096], y[:4096], chunk_size=4096, device=DEV)
+    o2 = torch.zeros_like(vec)
+    cg._matvec(ds2, kern, vec, o2, add_ridge=False)
+    assert float((o2 - ref_part).abs().max()) <= 1e-6 * float(ref_part.abs().max())
+
+
 @pytest.mark.parametrize("m,k,with_pre", [(512, 26, True), (2100, 3, False), (12288, 26, True), (4096, 2, True)])
 def test_block_device_solve_equals_the_generic_loop(m, k, with_pre, monkeypatch):
     """The batched solve with its vector updates in two kernels per iteration (hipCGStep1Block / hipCGStep2Block, errors

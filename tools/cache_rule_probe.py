@@ -1,6 +1,6 @@
 """k = 1 matvec: regenerating the features against streaming the resident float32 cache, at shapes each plan of
 xgpr_ztz_matvec_plan serves -- the numbers behind SORFKernel.cache_pays() (cache_features="auto").
-    python tools/cache_rule_probe.py [out.json]"""
+    python tools/cache_rule_probe.py [out.json] [--rows=N]"""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
@@ -13,8 +13,12 @@ shapes = [(1024, 8192), (256, 4096),                 # plan 1 (cfg3, cfg2)
           (512, 10240), (512, 14336), (1024, 16384), # 5, 7, 8 tiles
           (64, 4096), (20, 2048), (32, 8192),        # padded width < 128
           (1022, 8192),                              # d % 4 != 0
-          (512, 32768)]                              # two passes
-n = 131072
+          (512, 32768),                              # two passes
+          (64, 8192), (16, 8192),                    # tabular widths on the three-wave kernel (round 5)
+          (2003, 4000), (1076, 8192), (4000, 8192)]  # wide transforms (round 6)
+args = [a for a in sys.argv[1:] if not a.startswith("--rows=")]
+n = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--rows=")), 131072)
+sys.argv = sys.argv[:1] + args
 res = []
 g = torch.Generator(device=dev).manual_seed(1)
 for d, m in shapes:

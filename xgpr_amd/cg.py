@@ -122,12 +122,13 @@ class ConjugateGrad:
             win = max(1024, min(n, self.BLOCK_WINDOW_BYTES // (4 * m)))
             if self._zwin is None or self._zwin.shape != (win, m) or self._zwin.device != vec.device:
                 self._zwin = torch.empty((win, m), dtype=torch.float32, device=vec.device)
-            ws = self._block_ws(win, kernel, k, vec.device)
             for lo in range(0, n, win):
                 hi = min(n, lo + win)
                 zc = self._zwin[:hi - lo]
                 kernel.fill_feature_cache(xs[lo:hi], zc)
-                kernel.ztz_block_cached(zc, vec, out, ws, accumulate=True)
+                # (per window: a SHORTER last window can need a larger workspace -- the split projection's partials are reserved
+                # for short launches only; _block_ws only grows)
+                kernel.ztz_block_cached(zc, vec, out, self._block_ws(hi - lo, kernel, k, vec.device), accumulate=True)
         else:
             for x, lengths in dataset.get_chunked_x_data():
                 zc = kernel.transform_x(x, lengths).to(torch.float32)
@@ -502,8 +503,12 @@ def _resolve_cache_mode(cache_features, kernel, dataset, block=False):
         # One right-hand side on the single-pass three-wave kernel: regenerating is at least as fast as the stream for a
         # long shard (kernels.py) -- but the stream has the smaller cost per launch, and below ~250 000 rows it wins:
         # 0.746 against 0.776 ms per iteration on a 125 000-row shard (cfg3 over 8 GPUs), 1.401 / 1.400 at 250 000,
-        # 2.731 / 2.636 at 500 000 (gpurun_out/r4/shard_*.json, `cached_z_mode`).
-        if dataset.get_local_ndatapoints() > SMALL_SHARD_ROWS:
+        # 2.731 / 2.636 at 500 000 (gpurun_out/r4/shard_*.json, `cached_z_mode`).  Only where that was measured: below padded
+        # width 128 the three-wave kernel regenerates a tile in 1.0-1.2 ns against the stream's 1.32-1.39 on a 125 000-row shard
+        # too (d = 16 / 32 / 64 at 8192 RFFs: 0.51 / 0.51 / 0.54 against 0.66 ms; profiles/r6_cache_rule_125k.json).
+        from .kernels import padded_dims
+        narrow = padded_dims(dataset.get_xdim()[-1]) < 128
+        if dataset.get_local_ndatapoints() > SMALL_SHARD_ROWS or narrow:
             return False
     free, _total = torch.cuda.mem_get_info(torch.device(kernel.device))
     return 1.5 * dataset.feature_cache_bytes(kernel) + 2e9 < free
