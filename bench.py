@@ -44,6 +44,39 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # dense FP64 matrix peak: 256 CUs x 4 SIMDs x 2048 flop / 64 cycles x 2.4 GHz
 
 
+PROFILE_ROUND = "r6"          # the committed rocprofv3 summaries this file quotes: profiles/r6_*
+
+
+def stored_profile(name, build_id=None):
+    """(object, note) of profiles/<PROFILE_ROUND>_<name>.  With ``build_id``: a stored MEASUREMENT of a kernel is quoted only
+    while the library that produced it is the one loaded now (the summaries record xgpr_build_id() of the run they came from);
+    on a mismatch the object is None and the note says why -- a stale figure is not carried silently across kernel changes."""
+    path = os.path.join(ROOT, "profiles", "%s_%s" % (PROFILE_ROUND, name))
+    try:
+        obj = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "profiles/%s_%s is missing" % (PROFILE_ROUND, name)
+    if build_id is not None and obj.get("build_id") != build_id:
+        return None, ("profiles/%s_%s was measured on build %s; the loaded library is %s: not quoted (re-run tools/collect_profiles.sh)"
+                      % (PROFILE_ROUND, name, str(obj.get("build_id"))[:12], build_id[:12]))
+    return obj, "profiles/%s_%s" % (PROFILE_ROUND, name)
+
+
+def mfma_busy_of(kernels):
+    """SQ_VALU_MFMA_BUSY_CYCLES over SIMD-cycles for the named kernels, from the short-launch counter pass
+    (tools/r6_mfma_busy.sh -> profiles/r6_mfma_clock.json; stored)."""
+    obj, src = stored_profile("mfma_clock.json")
+    if obj is None:
+        return None
+    out = {}
+    for k in kernels:
+        ent = (obj.get(k) or [None])[0]
+        if ent:
+            out[k] = {"mfma_busy_frac_of_simd_cycles": ent["mfma_busy_frac_of_simd_cycles"], "clock_GHz": ent["clock_GHz"], "rows": ent["rows"]}
+    out["source"] = src + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE on launches short enough not to stop the counter; stored)"
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -326,7 +359,7 @@ def conv_featgen_probe(device, nseq=8192):
     """The convolution feature operator (cudaConv1dFGen's drop-in) at BASELINE configs[3]'s shape: one-hot protein-like
     sequences, L <= 512, 21 channels, conv_width 9, 16384 RFFs, 'sqrt' averaging; 8192 sequences per call (the window the
     feature cache is built in).  The kernel is vector-pipe bound: `priced` is count x measured issue cost of its k-mer
-    loop (profiles/r5_conv_inst_table.json, tools/count_loop_insts.py conv 8) over the measured time."""
+    loop (profiles/r6_conv_inst_table.json, tools/count_loop_insts.py conv 8) over the measured time."""
     import numpy as np
     import torch
     from xgpr_amd.kernels import make_kernel
@@ -352,11 +385,11 @@ def conv_featgen_probe(device, nseq=8192):
            "ms": ms, "sequences_per_s": nseq / (ms * 1e-3), "kmers": kmers, "tile_transforms_per_s": tiles / (ms * 1e-3),
            "note": "whole operator call (transform_x: scaling of the input copy, ordering kernel, feature kernel, float64 output)"}
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r5_conv_inst_table.json")))
+        tab = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_conv_inst_table.json")))
         pipe_ms = tab["priced_vector_ns_per_tile_per_simd"] * tiles / 1024 * 1e-6
         out["vector_pipe"] = {"valu_insts_per_kmer_tile": tab["valu_instructions"],
                               "priced": {"pipe_ms": pipe_ms, "frac": pipe_ms / ms,
-                                         "source": "profiles/r5_conv_inst_table.json x profiles/r3_valu_cost.json (stored)"}}
+                                         "source": "profiles/%s_conv_inst_table.json x profiles/r3_valu_cost.json (stored)" % PROFILE_ROUND}}
     except (OSError, KeyError, ValueError):
         pass
     return out
@@ -481,6 +514,131 @@ def nmll_probe(device, rows=262144):
     del zc, ds, pre, x, y
     torch.cuda.empty_cache()
     return out
+
+
+def wide_probe(device, rows=131072):
+    """Padded input widths beyond 1024 (round 6: transforms of two / four wave tiles on the three-wave kernel, one
+    cross-wave exchange per round) at the reference's own test shapes (tests/fht_operations_tests/test_rbf_rfgen.py:37,41:
+    d = 2003 / M = 4000, d = 1076 / M = 8192) and at d = 4000 / M = 8192: the float64 feature operator, one CG matvec the
+    way ``ConjugateGrad._matvec`` routes it (fused, features regenerated), the same over the resident float32 cache, z^T y and
+    a rank-512 preconditioner build -- beside what the any-width LDS path + materialised float64 Z took on the round-5 tree
+    (profiles/r6_generic_path_before.json)."""
+    import numpy as np
+    import torch
+    from xgpr_amd.kernels import make_kernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.cg import ConjugateGrad, calc_zty
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    before = {}
+    try:
+        for r in json.load(open(os.path.join(ROOT, "profiles", "r6_generic_path_before.json")))["shapes"]:
+            before[(r["d"], r["num_rffs"])] = r
+    except (OSError, KeyError, ValueError):
+        pass
+
+    def ev_ms(fn, reps=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    out = {"rows": rows, "shapes": []}
+    g = torch.Generator(device=device).manual_seed(7)
+    for d, m in ((2003, 4000), (1076, 8192), (4000, 8192)):
+        x = torch.randn(rows, d, device=device, generator=g) / d ** 0.5
+        y = torch.randn(rows, dtype=torch.float64, device=device, generator=g)
+        kern = make_kernel("RBF", (rows, d), m, 123, device, {})
+        kern.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+        ds = build_regression_dataset(x, y, chunk_size=16384, device=device)
+        xs = ds.scaled_x(kern.hyperparams[1])
+        tiles = rows * ((m // 2 + 1023) // 1024)
+        z = torch.empty(32768, m, dtype=torch.float64, device=device)
+
+        def featgen():
+            for lo in range(0, rows, 32768):
+                ext.hipRBFFeatureGen(xs[lo:lo + 32768], z[:min(32768, rows - lo)], kern.radem_diag, kern.chi_arr, True)
+        fg = ev_ms(featgen)
+        del z
+        vec = torch.randn(m, 1, dtype=torch.float64, device=device, generator=g)
+        w = torch.zeros_like(vec)
+        mv = ev_ms(lambda: ConjugateGrad(cache_features=False)._matvec(ds, kern, vec, w))
+        cgc = ConjugateGrad(cache_features=True)
+        wv = torch.zeros(m, dtype=torch.float64, device=device)
+        t0 = time.perf_counter()
+        ds.feature_cache(kern)
+        torch.cuda.synchronize()
+        t_cache = time.perf_counter() - t0
+        mvc = ev_ms(lambda: cgc._ztz(ds, kern, vec[:, 0].contiguous(), wv))
+        ds._zcache = None
+        ds._zcache_key = None
+        zty = ev_ms(lambda: calc_zty(ds, kern), reps=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pre = RandNysPreconditioner(kern, ds, 512, False, 123, "srht")
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter() - t0
+        b = before.get((d, m), {})
+        out["shapes"].append({
+            "d": d, "num_rffs": m, "padded_width": 1 << int(np.ceil(np.log2(d))), "wave_tiles_per_transform": (1 << int(np.ceil(np.log2(d)))) // 1024,
+            "matvec_plan": ext.ztz_matvec_plan(d, m // 2), "cache_features_auto": bool(kern.cache_pays()),
+            "featgen_f64_ms": fg, "featgen_GBs": (4.0 * d + 8.0 * m) * rows / (fg * 1e-3) / 1e9,
+            "cg_matvec_regenerating_ms": mv, "cg_matvec_ns_per_tile": mv * 1e6 / tiles,
+            "cg_matvec_cached_ms": mvc, "feature_cache_build_s": t_cache, "zty_ms": zty,
+            "precond_build_rank512_s": t_pre, "achieved_ratio": float(pre.achieved_ratio),
+            "round5_tree": {"featgen_f64_ms": b.get("featgen_f32_ms"), "cg_matvec_ms": b.get("cg_matvec_ms"), "zty_ms": b.get("zty_ms"),
+                            "precond_build_rank512_s": None if "precond_build_rank512_ms" not in b else b["precond_build_rank512_ms"] * 1e-3,
+                            "source": "profiles/r6_generic_path_before.json (generic_sorf_kernel + float64 Z + library GEMV; stored)"}})
+        del pre, ds, kern, x, y, xs
+        torch.cuda.empty_cache()
+    out["note"] = ("fit() at d > 1024 runs the same fused / cached / matrix-core paths as at d <= 1024 since round 6; per 1024-frequency "
+                   "tile the regenerating matvec takes ~1.2x (padded width 2048) / ~1.6x (4096) the padded-width-1024 time, so "
+                   "cache_features='auto' keeps Z resident there")
+    return out
+
+
+def notebook_tabular(device):
+    """The one published number that touches this path (/root/reference/docs/notebooks/
+    tabular_example.ipynb:547-560): ``fit(mode="cg", tol=1e-6)`` of an RBF model with 8192 RFFs on the UCI CASP training split
+    -- 36 584 rows x 9 standardised features, chunk_size 2000, preconditioner autoselected (the ratio check on a sample, then
+    a rank-512 srht build), CG, variance with variance_rffs = 512 -- 3.18 s wall on an unnamed NVIDIA GPU with xGPR 0.4.8
+    (35 CG iterations on the real data).  Here: synthetic rows of that shape (no network for the dataset), the notebook's
+    hyperparameters, the same call through the drop-in harness (xgpr_amd.models.xGPRegression.fit).  Context, not the target."""
+    import numpy as np
+    import torch
+    from xgpr_amd.models import xGPRegression
+    from xgpr_amd.dataset import build_regression_dataset
+    n, d = 36584, 9
+    rng = np.random.default_rng(123)
+    x = rng.standard_normal((n, d))
+    a = rng.standard_normal(d)
+    y = 6.0 * np.sin(x @ a / np.sqrt(d)) + 0.5 * (x[:, 0] * x[:, 1]) + 4.0 * rng.standard_normal(n) + 7.7
+    ds = build_regression_dataset(x, y, chunk_size=2000, device=device)
+    hp = np.array([-0.5406061, 0.2469573])          # tabular_example.ipynb cell 14 (log lambda, log sigma)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        warm = xGPRegression(num_rffs=8192, variance_rffs=512, kernel_choice="RBF", verbose=False, device=device, random_seed=123)
+        dsw = build_regression_dataset(x[:4000], y[:4000], chunk_size=2000, device=device)
+        warm.set_hyperparams(hp, dsw)
+        warm.fit(dsw, mode="cg", tol=1e-6)          # first launches / library initialisation: untimed
+        del warm, dsw
+        model = xGPRegression(num_rffs=8192, variance_rffs=512, kernel_choice="RBF", verbose=False, device=device, random_seed=123)
+        model.set_hyperparams(hp, ds)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_iter, losses = model.fit(ds, mode="cg", tol=1e-6, run_diagnostics=True)
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t0
+    return {"workload": "xGPRegression.fit(mode='cg', tol=1e-6): RBF, 36584 x 9 synthetic standardised rows (the CASP training split's shape), "
+                        "8192 RFFs, autoselected rank-512 srht preconditioner, variance_rffs 512, chunk_size 2000",
+            "seconds": t_fit, "cg_iterations": int(n_iter), "final_err": float(losses[-1]),
+            "reference": {"seconds": 3.184, "cg_iterations": 35, "hardware": "unnamed NVIDIA GPU, xGPR 0.4.8, real CASP data read from .npy chunks on disk",
+                          "source": "/root/reference/docs/notebooks/tabular_example.ipynb:547-560"},
+            "note": "context only: different hardware, synthetic data of the same shape (iteration counts differ), data resident on the device here"}
 
 
 def valu_only_probe(kern, ds, kern_ms, device):
@@ -746,16 +904,15 @@ def main():
         ck_ms = float(np.mean([a.elapsed_time(b) for a, b in ctimes]))
         kern.ztz_matvec_cached = origc
         cbytes = 4.0 * m * (hi - lo)
-        ctraffic = None
-        try:   # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (profiles/r5_pmc_traffic_cached.json; stored)
-            ctraffic = cbytes * json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic_cached.json")))["traffic_over_algorithmic"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # PMC-measured HBM bytes / algorithmic bytes of this streaming kernel (stored; quoted while the library is the measured build)
+        from xgpr_amd import _lib as xlib0
+        cpm, ctraffic_src = stored_profile("pmc_traffic_cached.json", xlib0.build_id())
+        ctraffic = cbytes * cpm["traffic_over_algorithmic"] if cpm and "traffic_over_algorithmic" in cpm else None
         cached = {"ms_per_step": 1e3 * float(tc.item()) / args.steps, "cg_iters_per_sec": args.steps / float(tc.item()),
                   "cache_bytes_per_gpu": cbytes, "cache_build_s": cache_build_s, "cache_alloc_s": cache_alloc_s,
                   "roofline": {"kernel": "zcache_ztz_kernel<true, 2> (+ reduce_slabs)", "bound": "hbm",
                                "achieved": cbytes / (ck_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": cbytes / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ctraffic,
+                               "frac": cbytes / (ck_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ctraffic, "traffic_source": ctraffic_src,
                                "algorithmic_bytes": cbytes, "kernel_ms": ck_ms},
                   "note": "features generated once (cache_build_s) and streamed; NOT the headline number"}
         # the block of right-hand sides of the approximate NMLL (k = 26) over the same resident cache: the
@@ -784,6 +941,7 @@ def main():
                              "achieved": bflop / (b_ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": bflop / (b_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                              "issued": bflop * 28 / kb / (b_ms * 1e-3) / 1e12, "traffic": None,
+                             "mfma_busy": mfma_busy_of(("zblock_t_kernel", "zblock_w_kernel")),
                              "algorithmic_flops": bflop},
                 "note": "26 right-hand sides run as 16 + 3 x 4 columns: 'issued' counts the 28 columns of MFMA work; "
                         "DESIGN.md section 3 (block of right-hand sides)"}
@@ -821,6 +979,8 @@ def main():
         torch.cuda.empty_cache()
         configs = {c: config_share(c, device) for c in ("cfg2", "cfg4", "cfg5")}
         configs["nmll_k26"] = nmll_probe(device)
+        configs["wide"] = wide_probe(device)
+        configs["notebook_tabular"] = notebook_tabular(device)
 
     if comm.rank == 0:
         n_local = hi - lo
@@ -828,17 +988,22 @@ def main():
         # rocprofv3 --pmc passes of this same command, corrected as MI355X_MICROARCH.md prescribes;
         # profiles/r2_pmc_traffic.json), not a quantity of this run -- quoted only for the configuration it was
         # measured on, and labelled as such in the line
+        from xgpr_amd import _lib as xlib
+        build_id = xlib.build_id()     # sha256 of csrc/*, include/xgpr_hip.h and the compiler flags the LOADED library was built from
         traffic = None
+        pm, traffic_src = stored_profile("pmc_traffic.json", build_id)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")))
-            c = pm["config"]
-            if (c["rows_per_gpu"], c["dim"], c["rffs"]) == (n_local, d, m):
-                traffic = pm["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+            if pm is not None:
+                c = pm["config"]
+                if (c["rows_per_gpu"], c["dim"], c["rffs"]) == (n_local, d, m):
+                    traffic = pm["hbm_bytes_per_launch"]
+                else:
+                    traffic_src = "stored for another configuration: not quoted"
+        except (KeyError, ValueError):
             pass
         # the resource this kernel is actually bound by: the vector pipe.  Three readings, each labelled:
         #  issue_slots -- vector instructions per wave tile (static count of the loop's hot path from the disassembly,
-        #                 tools/count_loop_insts.py -> profiles/r5_ztz3_inst_table.json) x tiles / live kernel time, against
+        #                 tools/count_loop_insts.py -> profiles/r6_ztz3_inst_table.json) x tiles / live kernel time, against
         #                 one wave-instruction per TWO cycles per SIMD at 2.4 GHz (the rate of v_add_f32; most of this
         #                 kernel's instructions -- packed, DPP, float64, conversions -- occupy the pipe for four cycles,
         #                 cos/sin for eight, so this reading cannot reach 1)
@@ -849,7 +1014,7 @@ def main():
         #                 instruction stream, LDS traffic / barrier / prefetch compiled out), over the live kernel time
         vector_pipe = None
         try:
-            tab = json.load(open(os.path.join(ROOT, "profiles", "r5_ztz3_inst_table.json")))
+            tab = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_ztz3_inst_table.json")))
             if (d, m) == (1024, 8192):
                 tiles = n_local * ((m // 2 + 1023) // 1024)
                 peak_inst = 256 * 4 * 2.4e9 / 2
@@ -859,7 +1024,7 @@ def main():
                                "issue_slots": {"achieved": inst_s / 1e9, "peak": peak_inst / 1e9, "unit": "G wave-instructions/s",
                                                "frac": inst_s / peak_inst},
                                "priced": {"pipe_ms": pipe_ms, "frac": pipe_ms / kern_ms,
-                                          "source": "profiles/r5_ztz3_inst_table.json x profiles/r3_valu_cost.json (stored)"},
+                                          "source": "profiles/%s_ztz3_inst_table.json x profiles/r3_valu_cost.json (stored)" % PROFILE_ROUND},
                                "valu_only": valu_probe}
         except (OSError, KeyError, ValueError):
             pass
@@ -867,8 +1032,6 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         fg_bytes = (4.0 * d + 8.0 * m) * fg_rows
         fg_gbs = fg_bytes / (fg_ms * 1e-3) / 1e9
-        from xgpr_amd import _lib as xlib
-        build_id = xlib.build_id()     # sha256 of csrc/*, include/xgpr_hip.h and the compiler flags the LOADED library was built from
         out = {
             "metric": "random-features/sec (fused CG matvec; every CG iteration regenerates all N x M features)",
             "value": n * m * args.steps / t,
@@ -894,13 +1057,13 @@ def main():
                        "rows_per_gpu": n_local, "lambda": 0.1, "sigma": 1.0},
             "roofline": {"kernel": "ztz3_kernel<10> (+ pack_radem, reduce_slabs)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r5_pmc_traffic.json (rocprofv3 --pmc passes of this "
-                         "command; stored, not re-measured in this run)" if traffic is not None else None,
+                         "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc passes of this command on this build; "
+                         "stored, not re-measured in this run)") if traffic is not None else traffic_src,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": kern_ms,
                          "vector_pipe": vector_pipe,
                          "note": "HBM traffic of this kernel is only the X read; the binding resource is the vector pipe "
                                  "(butterflies, cos/sin, float64 dot + rank-1 update) at 3 waves/SIMD: vector_pipe, "
-                                 "profiles/r5_fused_pmc_sq.json, DESIGN.md section 3"},
+                                 "profiles/r6_fused_pmc_sq.json, DESIGN.md section 3"},
             "featgen_op": {"rows": fg_rows, "ms": fg_ms, "features_per_s": fg_rows * m / (fg_ms * 1e-3),
                            "roofline": {"bound": "hbm", "achieved": fg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": fg_gbs / HBM_PEAK_GBS, "traffic": None}},
@@ -922,6 +1085,7 @@ def main():
                                            "achieved": 2.0 * n * args.rank_precond * m / precond_build_s / 1e12 / args.gpus,
                                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                            "frac": 2.0 * n * args.rank_precond * m / precond_build_s / 1e12 / args.gpus / FP64_MFMA_PEAK_TFLOPS,
+                                           "mfma_busy": mfma_busy_of(("sketch_gemm_lds_kernel",)),
                                            "traffic": None},
                               "note": "whole build (feature rows, SRHT + sample, contraction, all-reduce, factorizations) over the "
                                       "flops of the contraction alone; per GPU"},

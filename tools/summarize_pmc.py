@@ -57,7 +57,7 @@ for short, kname, alg in (("fused", "ztz3_kernel<10, Z3_MATVEC>", 4.0 * d * n_lo
         continue
     fk, wk = mean_main(per[short]["FETCH_SIZE"]), mean_main(per[short]["WRITE_SIZE"])
     hbm = (2.0 * fk + wk) * 1024.0
-    out = {"round": int(ROUND[1:]), "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
+    out = {"round": int(ROUND[1:]), "build_id": bench.get("build_id"), "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
            "--steps 3 --warmup 1 --no-cpu-baseline", "kernel": kname,
            "config": {"rows_per_gpu": n_local, "dim": d, "rffs": m, "n_gpus": 1},
            "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk, "correction": note,
@@ -86,4 +86,5 @@ for short, kname, alg in (("sketch_gemm", "sketch_gemm_lds_kernel<false>", win *
         print(short, f"traffic/algorithmic = {hbm / alg:.4f}")
 if pre:
     pre["correction"] = note
+    pre["build_id"] = bench.get("build_id")
     json.dump(pre, open(os.path.join(P, f"{ROUND}_pmc_traffic_precond.json"), "w"), indent=1)
