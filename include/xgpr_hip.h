@@ -65,12 +65,20 @@ int xgpr_srht_f64(double *x, const int8_t *radem, long n, long dim, long radem_l
 /* ---- cudaRBFFeatureGen (xgpr_cuda_rfgen_cpp_ext.cpp:32-40)
  * x[n, d] (T), out[out_rows, num_rffs] (f64), radem[3, 1, radem_shape2] (int8),
  * chi[num_freqs] (T).  Like the reference's CUDA kernel (rbf_ops.cu:121-127) the output
- * is OVERWRITTEN: out[i, 2f] = s*cos(chi[f]*sorf(x_i)[f]), out[i, 2f+1] = s*sin(...). */
+ * is OVERWRITTEN: out[i, 2f] = s*cos(chi[f]*sorf(x_i)[f]), out[i, 2f+1] = s*sin(...).
+ * float32 input, padded width P <= 4096: wave-tile kernels (a transform of P = 2048 / 4096 elements spans two / four
+ * wave tiles with one cross-wave exchange per round); beyond that, the gradient operator beyond P = 1024 and every
+ * float64 overload: the any-width path (one workgroup per transform, butterflies in LDS).
+ * Numerics: the float32 argument of every cos / sin is bit-identical to the reference's (same butterfly order, no
+ * contraction).  For even log2(P) the three normalisers 2^(-log2(P)/2) are exact powers of two and are applied ONCE,
+ * folded into chi: intermediate values of the transform are P^(1/2) .. P^(3/2) times the reference's (round by round), so
+ * inputs whose transform the reference still holds finite overflow here once |x| exceeds roughly FLT_MAX / P^(3/2) (1e34 at
+ * P = 1024; 3e29 = FLT_MAX / P^3 for the worst-aligned input) -- untested territory, far outside sigma-scaled data. */
 size_t xgpr_rbf_workspace_bytes(long radem_shape2);
 /* Workspace for any SORF operator below (feature-gen, grad, conv, max-pool): covers the
- * packed sign masks of the float fast path (padded width <= 1024) and, for padded widths
- * beyond the LDS capacity (> 32768 float / > 16384 double), the global scratch of the
- * generic path.  `width` is the un-padded transform width (d, or conv_width * C);
+ * packed sign masks of the float wave-tile path (padded width <= 1024; for the float feature
+ * operator and the feature cache: <= 4096) and, for padded widths beyond the LDS capacity
+ * (> 32768 float / > 16384 double), the global scratch of the any-width path.  `width` is the un-padded transform width (d, or conv_width * C);
  * elem_size is sizeof(T). */
 size_t xgpr_sorf_workspace_bytes(long radem_shape2, long width, int elem_size);
 /* Workspace of the convolution operators (xgpr_conv1d_fgen_*, xgpr_conv_grad_*, xgpr_conv1d_maxpool_*) with room
@@ -157,18 +165,22 @@ int xgpr_conv1d_maxpool_f64(const double *x, float *out, const int8_t *radem, co
  * x[n, d] float32 ALREADY multiplied by sigma (sorf_kernel_baseclass.py:117); v, w_out
  * [num_rffs] f64.  lambda^2 * v is NOT added (the caller adds it after the all-reduce).
  * Deterministic: per-workgroup partial sums are combined in a fixed order.
- * Supported: padded width P = 2^ceil(log2(max(d,2))) <= 1024, num_freqs <= 65536 (one pass
- * over the datapoints up to num_freqs = 8192; beyond that a dot pass and an update pass per
- * window of 65536 datapoints, i.e. the features are generated twice).
+ * Supported: padded width P = 2^ceil(log2(max(d,2))) <= 4096, num_freqs <= 65536.  One pass over the
+ * datapoints while a workgroup can hold every tile (1024 frequencies) of a datapoint: up to num_freqs = 7168
+ * at P <= 1024, up to 4096 at P = 2048 / 4096 (xgpr_ztz_matvec_plan says which); beyond that -- and for EIGHT
+ * tiles, 7168 < num_freqs <= 8192, which do not divide the kernel's twelve waves -- a dot pass and an update pass
+ * per window of 131072 datapoints, i.e. the features are generated twice.
  * The call packs radem into sign masks at the head of the workspace first; radem == NULL says the
  * workspace still holds the masks of an earlier call with the same radem (a CG solve calls this once per
  * iteration with one workspace), and the packing launch is skipped. */
 size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2);
 /* Which plan xgpr_ztz_matvec_f32 runs for rows of d floats (16-byte aligned) and num_freqs frequencies -- what a caller
  * that can also keep the features resident (xgpr_rbf_feature_cache_f32 + xgpr_zcache_matvec_f32) decides by:
- * 1 = one pass, three waves per SIMD (regenerating is as fast as streaming the cache); 2 = one pass, two-wave kernel
- * (seven tiles per datapoint, or one tile at padded width >= 128: slower than the cache stream); 3 = two feature passes (num_freqs > 8192, or eight tiles per datapoint: 7168 < num_freqs <= 8192);
- * 0 = unsupported shape. */
+ * 1 = one pass on the three-wave kernel (at padded width <= 1024 regenerating is as fast as streaming the cache; the wide
+ * transforms of padded width 2048 / 4096 cost 1.2x / 1.6x that per tile); 2 = one pass, two-wave kernel (seven tiles per
+ * datapoint, or one tile at padded width >= 128: slower than the cache stream); 3 = two feature passes (num_freqs > 8192;
+ * eight tiles per datapoint: 7168 < num_freqs <= 8192; more than 4096 frequencies at padded width > 1024);
+ * 0 = unsupported shape (padded width > 4096, num_freqs > 65536). */
 int xgpr_ztz_matvec_plan(long d, long num_freqs);
 int xgpr_ztz_matvec_f32(const float *x, const int8_t *radem, const float *chi, const double *v,
                         double *w_out, long n, long d, long num_rffs, long num_freqs,
