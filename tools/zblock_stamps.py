@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Where a matrix-pipe slot goes empty in the block matvec (zblock_t_kernel / zblock_w_kernel, k = 26): s_memtime stamps of
+sixteen steady-state chunk pairs in the first 64 workgroups of each contraction, from the -DXGPR_ZB_STAMPS development
+build (tools/ablate_build.sh zbstamps "-DXGPR_ZB_STAMPS"; never the shipped library).
+    python tools/zblock_stamps.py [rows] -> profiles/r6_zblock_stamps.json
+Per wave and chunk pair (two chunks of 32 features / datapoints between two workgroup barriers):
+  wait_1, wait_2   pair start (resp. end of the first chunk's MFMA issue) -> first MFMA of the chunk: the loads of the NEXT ring
+                   slots are issued here and the wave then waits for THIS chunk's streamed operand (issued three chunks ahead)
+  run_1, run_2     first MFMA of a chunk -> end of its MFMA issue (the wave shares its SIMD's matrix pipe with one partner wave)
+  tail             end of the second chunk -> barrier (next loads issued, the small operand of the next pair stored to LDS)
+  barrier          time inside the workgroup barrier
+The MFMA work of a wave per chunk is fixed: 8 steps x RT row tiles x (64 + 3 x 17) = 115 matrix cycles per operand element; a SIMD
+hosts two waves, so a pair holds 2 waves x 2 chunks of it per SIMD: `pipe_busy` = that over the pair's wall cycles."""
+import ctypes as C, json, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from xgpr_amd import _lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+m, k = 8192, 26
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(1)
+zc = torch.rand(n, m, device=dev, generator=g) * 2 - 1
+v = torch.randn(m, k, dtype=torch.float64, device=dev, generator=g)
+w = torch.empty_like(v)
+lib0 = _lib.load()
+ws = torch.empty(int(lib0.xgpr_zcache_block_workspace_bytes(n, m, k)), dtype=torch.uint8, device=dev)
+vp, l, i, d, sz = C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_size_t
+
+
+def bind(path):
+    lib = C.CDLL(path)
+    fn = lib.xgpr_zcache_block_matvec_f32
+    fn.argtypes = [vp, vp, vp, l, l, l, i, d, i, vp, sz, vp]; fn.restype = C.c_int
+    return lib, fn
+
+
+def timed(fn, reps=5):
+    for _ in range(2):
+        assert fn(zc.data_ptr(), v.data_ptr(), w.data_ptr(), n, m, k, 1, 0.0, 0, ws.data_ptr(), ws.numel(), 0) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn(zc.data_ptr(), v.data_ptr(), w.data_ptr(), n, m, k, 1, 0.0, 0, ws.data_ptr(), ws.numel(), 0)
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+_, fn_ship = bind(_lib.LIB_PATH)
+lib_s, fn_s = bind(os.path.join(ROOT, "tools", "ablate", "lib_zbstamps.so"))
+ms_ship = timed(fn_ship)
+ref = w.clone()
+ms_stamped = timed(fn_s)
+assert torch.equal(ref, w), "the stamped build must compute the same block matvec"
+WGS, PAIRS, NS = 64, 16, 8
+buf = np.zeros((2, WGS, 8, PAIRS, NS), dtype=np.uint64)
+lib_s.xgpr_debug_zb_stamps.argtypes = [vp, sz]; lib_s.xgpr_debug_zb_stamps.restype = C.c_int
+torch.cuda.synchronize()
+assert lib_s.xgpr_debug_zb_stamps(buf.ctypes.data, buf.nbytes) == buf.size
+out = {"what": "block matvec k = 26, %d x %d float32 rows; s_memtime stamps of %d steady-state chunk pairs x 8 waves x %d workgroups per kernel "
+               "(development build -DXGPR_ZB_STAMPS, results identical to the shipped build)" % (n, m, PAIRS, WGS),
+       "ms_per_block_matvec": {"shipped": ms_ship, "stamped_build": ms_stamped}}
+rt = 4 if n >= 2 * 256 * 512 else 2 if n >= 2 * 256 * 256 else 1
+for ki, (name, chunk_elems) in enumerate((("zblock_t_kernel", 8 * rt), ("zblock_w_kernel", 8 * 4))):
+    s = buf[ki].astype(np.int64)                                  # [wg, wave, pair, stamp]
+    ok = (s[..., 0] > 0) & (s[..., 6] > s[..., 0])
+    seg = {"wait_1": s[..., 1] - s[..., 0], "run_1": s[..., 2] - s[..., 1], "wait_2": s[..., 3] - s[..., 2], "run_2": s[..., 4] - s[..., 3],
+           "tail": s[..., 5] - s[..., 4], "barrier": s[..., 6] - s[..., 5], "pair": s[..., 6] - s[..., 0]}
+    pair = seg["pair"][ok]
+    mfma_cycles_per_wave_chunk = chunk_elems * 115
+    ent = {"workgroups_with_stamps": int(ok.any(axis=(1, 2)).sum()), "pairs_sampled": int(ok.sum()),
+           "cycles_per_pair_median": float(np.median(pair)),
+           "mfma_cycles_per_wave_per_chunk": mfma_cycles_per_wave_chunk,
+           "pipe_busy_from_stamps": float(2 * 2 * mfma_cycles_per_wave_chunk / np.median(pair)),
+           "segments_median_cycles": {k2: float(np.median(v2[ok])) for k2, v2 in seg.items()},
+           "segments_mean_frac_of_pair": {k2: float((v2[ok] / seg["pair"][ok]).mean()) for k2, v2 in seg.items() if k2 != "pair"},
+           "segments_p90_cycles": {k2: float(np.percentile(v2[ok], 90)) for k2, v2 in seg.items()}}
+    # a wave's MFMA run against what the pipe needs for it alone / shared with its partner
+    run = np.concatenate([seg["run_1"][ok], seg["run_2"][ok]])
+    ent["run_over_own_mfma_cycles_median"] = float(np.median(run) / mfma_cycles_per_wave_chunk)
+    out[name] = ent
+    print(name, json.dumps(ent))
+out["reading"] = ("run_over_own_mfma_cycles = 2.0 would be two waves alternating on a saturated pipe; each wave spends wait_1 + wait_2 + tail + barrier of a pair "
+                  "NOT issuing matrix instructions, and while it does its partner has the pipe alone -- a single wave issues a float64 MFMA "
+                  "only every ~140 cycles (tools/mfma_probe.hip), i.e. the pipe runs at about half rate for that time")
+json.dump(out, open(os.path.join(ROOT, "profiles", "r6_zblock_stamps.json"), "w"), indent=1)

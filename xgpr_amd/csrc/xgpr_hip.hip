@@ -432,6 +432,14 @@ int xgpr_srht_sample_f32(const float *z, const int8_t *radem, const long *sample
                                    workspace_bytes, stream);
 }
 
+#ifdef XGPR_ZB_STAMPS      /* development build only (tools/zblock_stamps.py): copies the stamp buffer of zblock.inc to the host */
+int xgpr_debug_zb_stamps(void *dst, size_t bytes) {
+    if (bytes > sizeof(g_zb_stamps)) bytes = sizeof(g_zb_stamps);
+    HIP_TRY(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_zb_stamps), bytes), "hipMemcpyFromSymbol(g_zb_stamps)");
+    return (int)(sizeof(g_zb_stamps) / 8);
+}
+#endif
+
 int xgpr_selftest_lane_xor(int32_t *out, void *stream) {
     hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
     HIP_TRY(hipGetLastError(), "selftest_kernel launch");
