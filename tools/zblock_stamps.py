@@ -83,4 +83,19 @@ for ki, (name, chunk_elems) in enumerate((("zblock_t_kernel", 8 * rt), ("zblock_
 out["reading"] = ("run_over_own_mfma_cycles = 2.0 would be two waves alternating on a saturated pipe; each wave spends wait_1 + wait_2 + tail + barrier of a pair "
                   "NOT issuing matrix instructions, and while it does its partner has the pipe alone -- a single wave issues a float64 MFMA "
                   "only every ~140 cycles (tools/mfma_probe.hip), i.e. the pipe runs at about half rate for that time")
+out["experiments_round_6"] = {
+    "how": "tools/ab_block.py (same process, interleaved builds, 262144 x 8192 float32 rows, identical results), tools/ablate_build.sh variants",
+    "three_waves_per_simd": {"what": "zblock_t_kernel with twelve-wave workgroups of RT = 2 row tiles (<= 168 VGPRs) instead of eight waves of RT = 4 (-DXGPR_ZB_T12)",
+                             "ms_k26": {"shipped": 3.905, "twelve_waves": 4.136}, "ms_k16": {"shipped": 2.892, "twelve_waves": 2.975},
+                             "ms_k32": {"shipped": 4.274, "twelve_waves": 4.457}, "reading": "slower: each LDS read of the small operand feeds half the MFMAs"},
+    "falling_priority": {"what": "s_setprio 3, 2 | 1, 0 by half chunk through a barrier interval (-DZB_PRIO=1), as in the fused matvec",
+                         "t_kernel_barrier_frac_of_interval": {"off": 0.171, "on": 0.110}, "t_kernel_cycles_per_pair": {"off": 17564, "on": 17274},
+                         "w_kernel_barrier_frac_of_interval": {"off": 0.070, "on": 0.059},
+                         "ms_k26": {"off": 3.875, "on": 3.922}, "ms_k16": {"off": 2.906, "on": 2.917}, "ms_k32": {"off": 4.259, "on": 4.268},
+                         "reading": "the waves reach the barrier together, the interval gets 1.7 % shorter in cycles, the launch does not (the clock gives it back)"},
+    "earlier_rounds": "r3: no loads at all -> 0.98 of the issue peak at the clock; per-wave private staging without the barrier -> no gain; r4: W on a window resident in the "
+                      "Infinity Cache -> 4 % (profiles/r3_block_ceiling.json, r4_mall_probe.json)",
+    "conclusion": "the pipe is 0.84-0.86 busy; what is missing is spread over the two operand waits of a chunk pair (10 % of a wave's interval), the tail (4-5 %) and the barrier "
+                  "(6-17 %), during each of which the wave's SIMD partner has the matrix pipe alone at about half its rate.  Neither more waves, nor balanced arrival, nor "
+                  "a barrier-free staging, nor a cache-resident stream shortens the launch: k = 26 stays at 0.70-0.73 of the FP64 matrix peak (0.82 issued at the clock)"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r6_zblock_stamps.json"), "w"), indent=1)
