@@ -377,3 +377,63 @@ def test_generic_width_paths_under_load_match_the_oracle_on_sampled_rows(oracle,
     scale = np.sqrt(1.0 / (m // 2))
     tol = 4e-7 if dtype == np.float32 else 1e-12
     assert np.abs(out[torch.from_numpy(pick).to(DEV)].cpu().numpy() - ref).max() <= tol * scale * (1 if dtype == np.float32 else 1e3)
+
+
+@pytest.mark.parametrize("n,d,m", [(200_000, 2003, 4000), (131_072, 1076, 8192), (120_000, 4000, 8192), (100_000, 2048, 16_384),
+                                   (90_000, 3000, 12_290)])
+def test_wide_transforms_under_load(oracle, n, d, m):
+    """Padded widths 2048 / 4096 (round 6): a transform spans two / four wave tiles whose waves meet once per round -- on counters in
+    LDS at 2048, at workgroup barriers at 4096 -- and the row image is single-buffered behind those meetings.  That kind of ordering
+    fails under load or not at all: launches that fill the chip (one and two passes), (1) reproducible bit for bit, (2) the sum of
+    their row shards, (3) sampled rows of the float64 operator and of the float32 cache against the CPU oracle (a stale tile of ANOTHER
+    wave would show in every frequency of the transform), (4) the fused matvec against the cached stream of the same features."""
+    from oracle import oracle as orc
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    from xgpr_amd.kernels import make_kernel
+    k = make_kernel("RBF", (n, d), m, 123, DEV, {})
+    k.set_hyperparams(np.array([0.1, 1.0]), logspace=False)
+    assert k.fused_ok() and k.cache_ok() and ext.ztz_matvec_plan(d, m // 2) in (1, 3)
+    x = _data(n, d, seed=d)
+    g = torch.Generator(device=DEV).manual_seed(m)
+    v = torch.randn(m, dtype=torch.float64, device=DEV, generator=g)
+    y = torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+    ws = torch.empty(k.workspace_bytes(), dtype=torch.uint8, device=DEV)
+    full, again, part = (torch.empty_like(v) for _ in range(3))
+    k.ztz_matvec(x, v, full, ws)
+    k.ztz_matvec(x, v, again, ws)
+    assert torch.equal(full, again) and bool(torch.isfinite(full).all())
+    parts = torch.zeros_like(v)
+    bounds = [0, n // 3 + 5, n // 2 + 1, n]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        k.ztz_matvec(x[lo:hi], v, part, ws)
+        parts += part
+    assert float((full - parts).abs().max() / full.abs().max()) < 1e-12
+    zty, zty2 = torch.empty_like(v), torch.empty_like(v)
+    k.zty(x, y, zty, ws)
+    k.zty(x, y, zty2, ws)
+    assert torch.equal(zty, zty2)
+    # sampled rows of both feature forms against the oracle
+    rows = min(n, 65_536)
+    zc = torch.empty((rows, m), dtype=torch.float32, device=DEV)
+    ext.hipRBFFeatureCache(x[:rows], zc, k.radem_diag, k.chi_arr)
+    z = torch.zeros((32_768, m), dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(x[:32_768], z, k.radem_diag, k.chi_arr, True)
+    rng = np.random.default_rng(n)
+    pick = np.sort(rng.choice(32_768, 160, replace=False))
+    pt = torch.from_numpy(pick).to(DEV)
+    ref = np.zeros((pick.shape[0], m))
+    oracle.cpuRBFFeatureGen(x[pt].cpu().numpy().copy(), ref, k.radem_diag.cpu().numpy(), k.chi_arr.cpu().numpy(), True)
+    scale = np.sqrt(1.0 / (m // 2 - 0.5))
+    assert np.abs(z[pt].cpu().numpy() - ref).max() <= 4e-7 * scale
+    assert np.abs(zc[pt].double().cpu().numpy() * float(np.float32(scale)) - ref).max() <= 4e-7 * scale
+    # the fused matvec of those rows == the cached stream of the same float32 features (1e-12: same values, float64 sums)
+    a, b = torch.empty_like(v), torch.empty_like(v)
+    k.ztz_matvec(x[:rows], v, a, ws)
+    k.ztz_matvec_cached(zc, v, b, ws)
+    assert float((a - b).abs().max() / a.abs().max()) < 1e-12
+    # ... and z^T y against the materialised features of the first rows
+    zt = torch.empty_like(v)
+    k.zty(x[:32_768], y[:32_768], zt, ws)
+    z[:, 0] = 1.0
+    refy = z.T @ y[:32_768]
+    assert float((zt - refy).abs().max() / refy.abs().max()) < 1e-9

@@ -29,12 +29,17 @@ def T(a):
 
 for case in range(cases):
     # (round 5: row lengths that are not multiples of 4, every padded width from 2 up, 5 / 7 / 8 tiles per datapoint)
-    d = int(rng.choice([2, 3, 7, 16, 20, 32, 33, 64, 100, 128, 130, 256, 300, 512, 617, 700, 1023, 1024]))
+    # (round 6: padded widths 2048 / 4096 -- transforms of two / four wave tiles)
+    d = int(rng.choice([2, 3, 7, 16, 20, 32, 33, 64, 100, 128, 130, 256, 300, 512, 617, 700, 1023, 1024, 1025, 1076, 1500, 2003, 2048, 2500, 3001,
+                        4000, 4096]))
     rffs = int(rng.choice([64, 512, 2048, 3000, 4096, 6144, 8192, 10000, 12288, 14000, 16384])) // 2 * 2
     n = int(rng.integers(1, 700))
+    if d > 1024:
+        n = int(rng.integers(1, 400))
     if case % 4 == 3 and rffs <= 4096:
-        n = int(rng.integers(20000, 60000))      # a launch that fills the chip: loads and stores in flight everywhere
+        n = int(rng.integers(20000, 60000) // (4 if d > 1024 else 1))      # a launch that fills the chip: loads and stores in flight everywhere
     icpt = bool(rng.integers(0, 2))
+    print(f"case {case} starts: d={d} M={rffs} n={n} icpt={icpt}", flush=True)
     radem, chi = orc.draw_sorf_params(rffs, d, int(rng.integers(1, 1000)))
     x = (rng.standard_normal((n, d)) / np.sqrt(d) * rng.choice([1.0, 1.0, 30.0, 3e5, 1e15])).astype(np.float32)     # (the last two: the rare cos/sin branch, beyond 2^31)
     z = np.zeros((n, rffs))
@@ -52,10 +57,19 @@ for case in range(cases):
     ext.hipZtZMatvec(T(x), T(radem), T(chi), T(v), w, icpt)
     ref = z.T @ (z @ v)
     fm_err = float(np.abs(w.cpu().numpy() - ref).max()); print(f"   fused matvec err / max|ref| = {fm_err / float(np.abs(ref).max()):.3e}", flush=True) if os.environ.get("STRESS_VERBOSE") else None
-    # (bar: 2e-6 of the largest entry.  The hardware cos/sin is within 4e-7 x scale per feature; for d = 3 (padded width 4:
-    # 256 transforms of one tile see the same three inputs) those errors add up coherently -- seed 406 case 13 reaches
-    # 1.38e-6, the same on every run; the path's requirement is 1e-5)
-    note("fused matvec", fm_err, 2e-6 * float(np.abs(ref).max()))
+    # Two bars.  (1) The kernel against the float64 product of the GPU's OWN feature matrix (checked entry by entry against the oracle
+    # above): the same float32 features, float64 sums -- 1e-9.  (2) Against the oracle's product: 2e-6 of the largest entry PLUS what
+    # 4e-7 x scale of independent error per feature adds up to over n x M terms (4 sigma).  Without that floor the bar is a lottery on the
+    # conditioning of the intercept component: w_0 = sum_i (z_i . v) can cancel to a few units (seed 601 case 19, d = 4000: |w_0| = 3.7
+    # where 250-500 is typical; tools/matvec_err_probe.py shows the same at d = 1024) while the accumulated cos/sin error does not shrink
+    # with it.  (d = 3: seed 406 case 13 reaches 1.38e-6 of the largest entry, the same on every run; the path's requirement is 1e-5.)
+    zg = out.clone()
+    if icpt:
+        zg[:, 0] = 1.0
+    wg = zg.T @ (zg @ T(v))
+    note("fused matvec vs own features", float((w - wg).abs().max()), 1e-9 * float(wg.abs().max()))
+    floor = 4.0 * 4e-7 * scale * np.sqrt(float(n) * rffs) * float(np.sqrt((v ** 2).mean()))
+    note("fused matvec", fm_err, 2e-6 * float(np.abs(ref).max()) + floor)
     zty = torch.zeros(rffs, dtype=torch.float64, device=dev)
     ext.hipZtY(T(x), T(radem), T(chi), T(y), zty, icpt)
     refy = z.T @ y
