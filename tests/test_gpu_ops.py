@@ -147,6 +147,38 @@ def test_rbf_vs_oracle(ext, oracle, d, rffs, icpt, n):
     check_features(out, ref, np.sqrt(1.0 / (F - 0.5 if icpt else F)))
 
 
+@pytest.mark.parametrize("d,rffs,icpt,n", [
+    # float64 wave tiles (64 <= padded width <= 1024, wave_f64.inc): every width, ragged rows and tiles, several transforms per tile
+    (33, 64, False, 9), (64, 2048, True, 70), (100, 300, False, 13), (128, 4096, True, 40), (200, 1026, False, 21), (256, 4096, True, 300),
+    (300, 1000, False, 6), (512, 16384, False, 30), (513, 4096, True, 50), (1000, 8192, True, 40), (1024, 8192, True, 260), (1024, 2050, False, 3),
+    # the any-width path: padded width < 64 and > 1024
+    (2, 16, False, 9), (7, 512, False, 17), (32, 512, True, 200), (1025, 4096, True, 3), (2003, 4000, False, 3)])
+def test_rbf_float64_vs_oracle(ext, oracle, d, rffs, icpt, n):
+    """The float64 overload of the feature operator (double_precision = True kernels, kernel_baseclass.py:278-285) against the oracle
+    in double: same butterfly order and per-round `radem * norm` product as shared_rfgen_ops.cpp:51-78, so the cos / sin arguments are
+    bit-identical and the features agree to the last digits of the two double-precision libms (1e-13 x scale)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(d * 11 + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, d, 321, double_precision=True)
+    x = rng.standard_normal((n, d)) * 2.0
+    ref = np.zeros((n, rffs))
+    oracle.cpuRBFFeatureGen(x.copy(), ref, radem, chi, icpt)
+    out = torch.full((n, rffs), 7.0, dtype=torch.float64, device=DEV)
+    ext.hipRBFFeatureGen(dev(x), out, dev(radem), dev(chi), icpt)
+    F = rffs // 2
+    check_features(out, ref, np.sqrt(1.0 / (F - 0.5 if icpt else F)), double=True)
+    out2 = torch.zeros_like(out)
+    ext.hipRBFFeatureGen(dev(x), out2, dev(radem), dev(chi), icpt)
+    assert torch.equal(out, out2)
+    # un-normalised rows: arguments beyond 2^20 leave the kernel's own reduction for the library's (rows on both sides of it in one launch)
+    xb = x * 3e6
+    xb[::3] = x[::3]
+    with np.errstate(all="ignore"):
+        oracle.cpuRBFFeatureGen(xb.copy(), ref := np.zeros((n, rffs)), radem, chi, icpt)
+    ext.hipRBFFeatureGen(dev(xb), out, dev(radem), dev(chi), icpt)
+    check_features(out, ref, np.sqrt(1.0 / (F - 0.5 if icpt else F)), double=True)
+
+
 @pytest.mark.parametrize("d,rffs,amp", [(50, 128, 3e4), (1024, 8192, 2e4), (256, 4096, 5e4), (20, 64, 1e6), (512, 2048, 3e9),
                                         (512, 2048, 1e15), (1024, 8192, 1e24), (40, 256, 1e28),
                                         # padded widths 2048 / 4096 (wide transforms: the argument is still bit-identical)
