@@ -279,6 +279,48 @@ def test_auto_cache_mode_keeps_features_resident_only_where_streaming_them_is_fa
     assert not k.cache_pays() and _resolve_cache_mode("auto", k, ds) is False
 
 
+@pytest.mark.parametrize("d,m,method", [(1500, 4096, "srht"), (2600, 8192, "srht_2"), (1100, 2048, "srht")])
+def test_fit_beyond_1024_features_equals_the_materialised_float64_path(d, m, method, monkeypatch):
+    """d > 1024 (padded width 2048 / 4096): the whole solve -- z^T y, the preconditioner's passes over float32 feature rows, the
+    fused / cached CG matvec, and the k = 26 block matvec -- on the wave-tile kernels (round 6) against the SAME solve with the
+    kernel's fused paths switched off, i.e. what rounds 1-5 ran there and what the reference does: float64 Z materialised chunk by
+    chunk by the any-width operator (an independent implementation: one workgroup per row, butterflies in LDS), library GEMV /
+    GEMM.  Same iteration count, weights to 1e-6 (the two feature matrices agree to 4e-7 x scale per entry), z^T y to 1e-7."""
+    from xgpr_amd.kernels import make_kernel, SORFKernel
+    from xgpr_amd.dataset import build_regression_dataset
+    from xgpr_amd.preconditioner import RandNysPreconditioner
+    from xgpr_amd.cg import cg_fit_lib_internal, calc_zty, ConjugateGrad
+    rng = np.random.default_rng(d)
+    n = 6000
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    y = np.sin(3.0 * x @ rng.standard_normal(d)) + 0.1 * rng.standard_normal(n)
+    ds = build_regression_dataset(x, y, chunk_size=2000, device=DEV)
+    out = {}
+    for fused in (True, False):
+        kern = make_kernel("RBF", x.shape, m, 123, DEV, {})
+        kern.set_hyperparams(np.array([0.3, 1.2]), logspace=False)
+        if not fused:
+            monkeypatch.setattr(SORFKernel, "fused_ok", lambda self: False)
+            monkeypatch.setattr(SORFKernel, "block_ok", lambda self: False)
+            assert not kern.fused_ok() and not kern.cache_ok()
+        else:
+            assert kern.fused_ok() and kern.cache_ok() and kern.block_ok()
+        zty, yty = calc_zty(ds, kern)
+        pre = RandNysPreconditioner(kern, ds, 128, False, 123, method)
+        w, niter, losses = cg_fit_lib_internal(kern, ds, 1e-7, 300, pre, False, cache_features="auto" if fused else False)
+        vec = torch.from_numpy(np.random.default_rng(1).standard_normal((m, 26))).to(DEV)
+        mv = torch.zeros_like(vec)
+        ConjugateGrad(cache_features=False)._matvec(ds, kern, vec, mv, add_ridge=False)
+        out[fused] = (zty, yty, float(pre.achieved_ratio), w, niter, mv)
+        monkeypatch.undo()
+    (za, ya, ra, wa, na, ma), (zb, yb, rb, wb, nb, mb) = out[True], out[False]
+    assert float((za - zb).abs().max() / zb.abs().max()) < 1e-7 and abs(ya - yb) <= 1e-12 * abs(yb)
+    assert abs(ra - rb) <= 1e-4 * rb
+    assert abs(na - nb) <= 1
+    assert float((wa - wb).abs().max() / wb.abs().max()) < 1e-5
+    assert float((ma - mb).abs().max() / mb.abs().max()) < 1e-6
+
+
 def test_cg_with_resident_feature_cache_matches_regenerating_cg():
     """cache_features=True (Z kept in HBM as float32, streamed each iteration) gives the same solve as
     the default (features regenerated each iteration): iteration counts within one at tol 1e-8, weights to 1e-7."""
