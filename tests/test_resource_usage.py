@@ -16,12 +16,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # register-limited waves per SIMD the design relies on: the fused matvec, the convolution feature
 # operator and the feature operator run three / three / six waves per SIMD
-# (round 6: the wide transforms -- padded width 2048 at three waves per SIMD like 1024; 4096 runs eight-wave workgroups, two per SIMD.
+# (round 6: the wide transforms -- padded widths 2048 and 4096 at three waves per SIMD like 1024 (4096: the row image aliases the exchange
+# buffers, fused_ztz.inc Z3_XALIAS; its feature modes run eight-wave workgroups).
 # The floor was rewritten once this round: generic_sorf_kernel<double, 2, true> 6 -> 5 with the fused double-precision sincos, which
 # measures 5-8 % faster on the float64 operator, profiles/r6_f64_op_ab.txt)
 HOT = {"ztz3_kernel<10, 0, false>": 3, "ztz3_kernel<8, 0, false>": 3, "ztz3_kernel<10, 1, false>": 3, "ztz3_kernel<10, 0, true>": 3, "wave_conv_kernel<8, 0>": 3,
        "wave_conv_kernel<10, 0>": 3, "wave_rbf_kernel<10, 0>": 6, "ztz3_kernel<11, 0, false>": 3, "ztz3_kernel<11, 0, true>": 3, "ztz3_kernel<11, 5, false>": 3,
-       "ztz3_kernel<12, 0, false>": 2, "ztz3_kernel<12, 5, false>": 2}
+       "ztz3_kernel<12, 0, false>": 3, "ztz3_kernel<12, 3, false>": 3, "ztz3_kernel<12, 5, false>": 3}
 
 
 @pytest.fixture(scope="module")
