@@ -426,6 +426,9 @@ def test_wide_transforms_under_load(oracle, n, d, m):
     scale = np.sqrt(1.0 / (m // 2 - 0.5))
     assert np.abs(z[pt].cpu().numpy() - ref).max() <= 4e-7 * scale
     assert np.abs(zc[pt].double().cpu().numpy() * float(np.float32(scale)) - ref).max() <= 4e-7 * scale
+    # EVERY row of the launch, not a sample: the float64 operator is the widening of the cache rows times its constant, bit for bit (two
+    # different launches of two feature modes: one row computed from a stale tile in either shows here -- tools/wide_consistency_probe.py)
+    assert torch.equal(zc[:32_768].double() * float(np.float32(scale)), z)
     # the fused matvec of those rows == the cached stream of the same float32 features (1e-12: same values, float64 sums)
     a, b = torch.empty_like(v), torch.empty_like(v)
     k.ztz_matvec(x[:rows], v, a, ws)
@@ -437,3 +440,19 @@ def test_wide_transforms_under_load(oracle, n, d, m):
     z[:, 0] = 1.0
     refy = z.T @ y[:32_768]
     assert float((zt - refy).abs().max() / refy.abs().max()) < 1e-9
+    # ... repeated on other row windows of the launch-filling sizes (every launch is a new draw of the timing)
+    for lo, cnt in ((n - 40_000, 32_768), (n // 3, 20_000), (n // 2 + 7, 30_001)):
+        xs, ys = x[lo:lo + cnt], y[lo:lo + cnt]
+        zf = torch.empty((cnt, m), dtype=torch.float64, device=DEV)
+        ext.hipRBFFeatureGen(xs, zf, k.radem_diag, k.chi_arr, True)
+        zr = torch.empty((cnt, m), dtype=torch.float32, device=DEV)
+        ext.hipRBFFeatureCache(xs, zr, k.radem_diag, k.chi_arr)
+        assert torch.equal(zr.double() * float(np.float32(scale)), zf)
+        zf[:, 0] = 1.0
+        k.zty(xs, ys, zt, ws)
+        ry = zf.T @ ys
+        assert float((zt - ry).abs().max() / ry.abs().max()) < 1e-10
+        k.ztz_matvec(xs, v, a, ws)
+        rm = zf.T @ (zf @ v)
+        assert float((a - rm).abs().max() / rm.abs().max()) < 1e-10
+        del zf, zr
