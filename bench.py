@@ -595,7 +595,7 @@ def wide_probe(device, rows=131072):
         del pre, ds, kern, x, y, xs
         torch.cuda.empty_cache()
     out["note"] = ("fit() at d > 1024 runs the same fused / cached / matrix-core paths as at d <= 1024 since round 6; per 1024-frequency "
-                   "tile the regenerating matvec takes ~1.2x (padded width 2048) / ~1.6x (4096) the padded-width-1024 time, so "
+                   "tile the regenerating matvec takes ~1.2x (padded width 2048) / ~1.5x (4096) the padded-width-1024 time, so "
                    "cache_features='auto' keeps Z resident there")
     return out
 

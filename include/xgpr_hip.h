@@ -177,7 +177,7 @@ size_t xgpr_ztz_matvec_workspace_bytes(long num_rffs, long radem_shape2);
 /* Which plan xgpr_ztz_matvec_f32 runs for rows of d floats (16-byte aligned) and num_freqs frequencies -- what a caller
  * that can also keep the features resident (xgpr_rbf_feature_cache_f32 + xgpr_zcache_matvec_f32) decides by:
  * 1 = one pass on the three-wave kernel (at padded width <= 1024 regenerating is as fast as streaming the cache; the wide
- * transforms of padded width 2048 / 4096 cost 1.2x / 1.6x that per tile); 2 = one pass, two-wave kernel (seven tiles per
+ * transforms of padded width 2048 / 4096 cost 1.2x / 1.5x that per tile); 2 = one pass, two-wave kernel (seven tiles per
  * datapoint, or one tile at padded width >= 128: slower than the cache stream); 3 = two feature passes (num_freqs > 8192;
  * eight tiles per datapoint: 7168 < num_freqs <= 8192; more than 4096 frequencies at padded width > 1024);
  * 0 = unsupported shape (padded width > 4096, num_freqs > 65536). */

@@ -34,5 +34,6 @@ import json
 l = [x for x in open('gpurun_out/prof_stats.json').read().strip().splitlines() if x.startswith('{')][-1]
 json.dump(json.loads(l), open('profiles/r6_bench_n1_line.json', 'w'), indent=1)
 PY
+python tools/wide_path_probe.py --rows 131072 --tag final --out profiles/r6_generic_path.json > gpurun_out/r6/generic_path_final.log 2>&1 || tail -5 gpurun_out/r6/generic_path_final.log
 cp profiles/r6_* gpurun_out/r6/profiles/
 ls gpurun_out/r6/profiles | wc -l
