@@ -107,3 +107,26 @@ def test_every_entry_point_is_mapped_in_integration_md():
             assert "xgpr_*_workspace_bytes" in doc or base in doc
         else:
             assert base in doc, f"{name} is not mentioned in INTEGRATION.md"
+
+
+def test_host_side_plans_and_workspaces_need_no_gpu():
+    """The launcher's shape predicates are host code: which plan the fused matvec takes by padded width and frequency count (round 6:
+    padded widths 2048 / 4096 on the wave-tile kernels), and workspace sizes that cover every plan of a shape (the two-pass row-window
+    buffer wherever ANY padded width could take two passes)."""
+    from xgpr_amd import _lib
+    lib = _lib.load()
+    plan = lambda d, f: int(lib.xgpr_ztz_matvec_plan(d, f))
+    # one pass on the three-wave kernel / two-wave kernel / two passes / unsupported
+    assert [plan(1024, 4096), plan(256, 1024), plan(1024, 8192), plan(512, 16384)] == [1, 2, 3, 3]
+    assert [plan(2000, 2000), plan(1025, 100), plan(4000, 4096), plan(2048, 4096), plan(3000, 1)] == [1, 1, 1, 1, 1]
+    assert [plan(2000, 4097), plan(4000, 8192), plan(4096, 65536)] == [3, 3, 3]
+    assert [plan(5000, 4096), plan(4097, 10), plan(100, 65537), plan(100, 0)] == [0, 0, 0, 0]
+    ws = lambda m, r: int(lib.xgpr_ztz_matvec_workspace_bytes(m, r))
+    slabs = lambda m: 2048 * m * 8
+    # up to 4096 frequencies no padded width takes two passes; beyond it the wide transforms do, beyond 7168 every width does
+    assert ws(8192, 4096) < slabs(8192) + (1 << 20)
+    assert ws(8194, 8192) >= slabs(8194) + 131072 * 5 * 8
+    assert ws(16384, 8192) >= slabs(16384) + 131072 * 8 * 8
+    # monotone in the feature count
+    sizes = [ws(m, 65536) for m in (2, 4096, 8192, 8194, 16384, 32768, 131072)]
+    assert sizes == sorted(sizes)
