@@ -1,5 +1,7 @@
+"""Feature rows at padded width 4096 (float64 operator in 32768-row windows, float32 cache rows) through the library XGPR_HIP_LIB names:
+    python tools/feat_wide_ab.py          (A/B of the aliased row image for the feature modes: profiles/r6_xalias_ab.txt)"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from xgpr_amd.kernels import make_kernel
 from xgpr_amd import xgpr_hip_rfgen_ext as ext
