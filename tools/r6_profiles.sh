@@ -32,6 +32,13 @@ tail -c 300 gpurun_out/prof_stats.json > /dev/null
 python - <<'PY'
 import json
 l = [x for x in open('gpurun_out/prof_stats.json').read().strip().splitlines() if x.startswith('{')][-1]
+json.dump(json.loads(l), open('profiles/r6_bench_n1_line_profiled.json', 'w'), indent=1)
+PY
+# the line of a plain run AFTER the traffic JSONs of this build exist (roofline.traffic quoted): the one a later `python bench.py` reproduces
+python bench.py > gpurun_out/r6/bench_final.json 2> gpurun_out/r6/bench_final.err
+python - <<'PY'
+import json
+l = [x for x in open('gpurun_out/r6/bench_final.json').read().strip().splitlines() if x.startswith('{')][-1]
 json.dump(json.loads(l), open('profiles/r6_bench_n1_line.json', 'w'), indent=1)
 PY
 python tools/wide_path_probe.py --rows 131072 --tag final --out profiles/r6_generic_path.json > gpurun_out/r6/generic_path_final.log 2>&1 || tail -5 gpurun_out/r6/generic_path_final.log
