@@ -50,7 +50,7 @@ def write_table(rows, out_file):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    out_file = args[0] if args else os.path.join(ROOT, "profiles", "r5_resource_usage.txt")
+    out_file = args[0] if args else os.path.join(ROOT, "profiles", "r6_resource_usage.txt")
     rows = collect()
     write_table(rows, out_file)
     bad = [r for r in rows if r.get("ScratchSize", 0)]
