@@ -465,9 +465,14 @@ def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
 
 
 @pytest.mark.parametrize("d,rffs,icpt,n", [(50, 128, False, 11), (256, 4096, True, 30), (856, 4000, True, 7),
-                                           (1024, 8192, False, 9), (1100, 2048, True, 5)])
+                                           (1024, 8192, False, 9), (1100, 2048, True, 5),
+                                           # padded widths 2048 / 4096: two / four waves of a workgroup per transform (wave_f64.inc, T = float)
+                                           (2003, 4000, False, 7), (1076, 8192, True, 3), (1500, 100, False, 11), (4000, 8192, True, 5),
+                                           (4096, 4100, False, 6), (3000, 16384, True, 2),
+                                           # the any-width path
+                                           (5000, 8192, True, 2)])
 def test_rbf_grad_vs_oracle(ext, oracle, d, rffs, icpt, n):
-    """cudaRBFGrad on the wave path (P <= 1024) and the generic path: features and d/dsigma against
+    """cudaRBFGrad on the wave kernels (P <= 4096) and the any-width path: features and d/dsigma against
     the oracle, including the reference's roundings back to float (shared_rfgen_ops.cpp:140-155)."""
     from oracle import oracle as orc
     rng = np.random.default_rng(d + rffs)
@@ -482,6 +487,31 @@ def test_rbf_grad_vs_oracle(ext, oracle, d, rffs, icpt, n):
     scale = np.sqrt(2.0 / rffs)
     assert np.abs(o.cpu().numpy() - ro).max() <= 4e-7 * scale
     assert np.abs(g.cpu().numpy() - rg).max() <= 1e-6 * np.abs(rg).max()
+
+
+@pytest.mark.parametrize("d,rffs,icpt,n", [(64, 2048, True, 70), (100, 300, False, 13), (200, 1026, False, 21), (513, 4096, True, 50),
+                                           (1024, 8192, True, 33), (1076, 8192, True, 7), (2003, 4000, False, 3), (4000, 8192, False, 9),
+                                           (3000, 1000, True, 6), (33, 64, False, 9), (5000, 8192, True, 2)])
+def test_rbf_grad_float64_vs_oracle(ext, oracle, d, rffs, icpt, n):
+    """The float64 overload of cudaRBFGrad (double_precision = True kernels) on the float64 wave tiles (64 <= P <= 4096) and on the any-width
+    path beyond: same stage order and per-round `radem * norm` product, so the argument and `grad_val` are bit-identical to the oracle's in
+    double and the outputs agree to the last digits of the two libms."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(d * 7 + rffs)
+    radem, chi = orc.draw_sorf_params(rffs, d, 19, double_precision=True)
+    x = rng.standard_normal((n, d)) / np.sqrt(d)
+    sigma = 1.3
+    ro, rg = np.zeros((n, rffs)), np.zeros((n, rffs, 1))
+    oracle.cpuRBFGrad(x.copy(), ro, rg, radem, chi, sigma, icpt)
+    o = torch.full((n, rffs), 7.0, dtype=torch.float64, device=DEV)
+    g = torch.full((n, rffs, 1), 7.0, dtype=torch.float64, device=DEV)
+    ext.hipRBFGrad(dev(x), o, g, dev(radem), dev(chi), sigma, icpt)
+    scale = np.sqrt(2.0 / rffs)
+    assert np.abs(o.cpu().numpy() - ro).max() <= 1e-13 * scale
+    assert np.abs(g.cpu().numpy() - rg).max() <= 1e-13 * max(np.abs(rg).max(), scale)
+    o2, g2 = torch.zeros_like(o), torch.zeros_like(g)
+    ext.hipRBFGrad(dev(x), o2, g2, dev(radem), dev(chi), sigma, icpt)
+    assert torch.equal(o, o2) and torch.equal(g, g2)
 
 
 @pytest.mark.parametrize("L,C,cw,rffs,sc,n", [(30, 21, 9, 1024, 1, 9), (17, 4, 1, 64, 0, 21), (40, 21, 5, 600, 2, 7)])
