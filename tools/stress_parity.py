@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU (development aid, not part of the test suite): random shapes through the fused
-matvec, z^T y, the feature operator, the cache rows, the block (k right-hand sides) matvec / projection and the
-convolution operator, each against the CPU oracle or a float64 torch product on the same inputs.
+matvec, z^T y, the feature operator (float32 and float64 input), the gradient operator (both), the cache rows, the block (k right-hand
+sides) matvec / projection and the convolution operator, each against the CPU oracle or a float64 torch product on the same inputs.
     python tools/stress_parity.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -91,6 +91,33 @@ for case in range(cases):
             ext.hipZCacheBlockProject(zc, V, P, icpt)
             refp = zs @ V
             note("block project", float((P - refp).abs().max()), 1e-11 * float(refp.abs().max()) + 1e-300)
+    # gradient operator, float32 (wave tiles at every padded width up to 4096) -- on un-amplified rows (sigma scales the argument)
+    ng = min(n, 300)
+    xg = (rng.standard_normal((ng, d)) / np.sqrt(d)).astype(np.float32)
+    sigma = float(rng.uniform(0.2, 3.0))
+    ro, rg = np.zeros((ng, rffs)), np.zeros((ng, rffs, 1))
+    oracle.cpuRBFGrad(xg.copy(), ro, rg, radem, chi, sigma, icpt)
+    og = torch.full((ng, rffs), 7.0, dtype=torch.float64, device=dev)
+    gg = torch.full((ng, rffs, 1), 7.0, dtype=torch.float64, device=dev)
+    ext.hipRBFGrad(T(xg), og, gg, T(radem), T(chi), sigma, icpt)
+    gscale = np.sqrt(2.0 / rffs)
+    note("grad features f32", float(np.abs(og.cpu().numpy() - ro).max()), 4e-7 * gscale)
+    note("grad f32", float(np.abs(gg.cpu().numpy() - rg).max()), 1e-6 * max(float(np.abs(rg).max()), gscale))
+    # float64 overloads: feature operator and gradient (float64 wave tiles at 64 <= padded width <= 4096, any-width path otherwise)
+    radem_d, chi_d = orc.draw_sorf_params(rffs, d, int(rng.integers(1, 1000)), double_precision=True)
+    xd = rng.standard_normal((ng, d)) / np.sqrt(d) * float(rng.choice([1.0, 1.0, 40.0, 1e5]))
+    zd = np.zeros((ng, rffs))
+    oracle.cpuRBFFeatureGen(xd.copy(), zd, radem_d, chi_d, icpt)
+    od = torch.full((ng, rffs), 7.0, dtype=torch.float64, device=dev)
+    ext.hipRBFFeatureGen(T(xd), od, T(radem_d), T(chi_d), icpt)
+    # cos / sin of a bit-identical argument by two double-precision libms: 1e-13 x scale at every amplitude
+    note("features f64", float(np.abs(od.cpu().numpy() - zd).max()), 1e-13 * scale)
+    xd1 = rng.standard_normal((ng, d)) / np.sqrt(d)
+    ro, rg = np.zeros((ng, rffs)), np.zeros((ng, rffs, 1))
+    oracle.cpuRBFGrad(xd1.copy(), ro, rg, radem_d, chi_d, sigma, icpt)
+    ext.hipRBFGrad(T(xd1), og, gg, T(radem_d), T(chi_d), sigma, icpt)
+    note("grad features f64", float(np.abs(og.cpu().numpy() - ro).max()), 1e-13 * gscale)
+    note("grad f64", float(np.abs(gg.cpu().numpy() - rg).max()), 1e-13 * max(float(np.abs(rg).max()), gscale))
     # convolution operator
     C = int(rng.choice([4, 21, 64])); cw = int(rng.integers(1, 17)); L = cw + int(rng.integers(0, 40))
     m2 = int(rng.choice([64, 600, 1024, 2048]))
