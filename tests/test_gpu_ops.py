@@ -148,15 +148,17 @@ def test_rbf_vs_oracle(ext, oracle, d, rffs, icpt, n):
 
 
 @pytest.mark.parametrize("d,rffs,icpt,n", [
-    # float64 wave tiles (64 <= padded width <= 4096, wave_f64.inc): every width, ragged rows and tiles, several transforms per tile
+    # float64 wave tiles (padded width <= 4096, wave_f64.inc): every width, ragged rows and tiles, several transforms per tile
+    (7, 512, False, 17), (32, 512, True, 200), (9, 8192, True, 77), (3, 2048, False, 31), (2, 128, True, 5), (20, 4096, True, 130), (16, 1000, False, 9),
+    (40, 3000, True, 21),
     (33, 64, False, 9), (64, 2048, True, 70), (100, 300, False, 13), (128, 4096, True, 40), (200, 1026, False, 21), (256, 4096, True, 300),
     (300, 1000, False, 6), (512, 16384, False, 30), (513, 4096, True, 50), (1000, 8192, True, 40), (1024, 8192, True, 260), (1024, 2050, False, 3),
     # padded widths 2048 / 4096: two / four waves per transform (a last workgroup with a spare pair: 3 rows x 2 tiles; tiles past the last
     # frequency; several transforms per row)
     (1025, 4096, True, 3), (2003, 4000, False, 3), (1076, 8192, True, 37), (2048, 2050, False, 5), (1500, 100, True, 11), (2049, 8192, True, 21),
     (4000, 8192, False, 19), (4096, 16384, True, 6), (3000, 1000, False, 9), (2500, 10000, True, 2),
-    # the any-width path: padded width < 64 and > 4096
-    (2, 16, False, 9), (7, 512, False, 17), (32, 512, True, 200), (5000, 8192, True, 2)])
+    # the any-width path: diagonals shorter than 64, padded width > 4096
+    (2, 16, False, 9), (5, 48, True, 12), (5000, 8192, True, 2)])
 def test_rbf_float64_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """The float64 overload of the feature operator (double_precision = True kernels, kernel_baseclass.py:278-285) against the oracle
     in double: same butterfly order and per-round `radem * norm` product as shared_rfgen_ops.cpp:51-78, so the cos / sin arguments are
@@ -491,9 +493,11 @@ def test_rbf_grad_vs_oracle(ext, oracle, d, rffs, icpt, n):
 
 @pytest.mark.parametrize("d,rffs,icpt,n", [(64, 2048, True, 70), (100, 300, False, 13), (200, 1026, False, 21), (513, 4096, True, 50),
                                            (1024, 8192, True, 33), (1076, 8192, True, 7), (2003, 4000, False, 3), (4000, 8192, False, 9),
-                                           (3000, 1000, True, 6), (33, 64, False, 9), (5000, 8192, True, 2)])
+                                           (3000, 1000, True, 6), (33, 64, False, 9), (5000, 8192, True, 2),
+                                           (9, 8192, True, 77), (3, 2048, False, 31), (2, 128, True, 5), (20, 4096, True, 130), (32, 512, False, 9),
+                                           (7, 16, False, 4)])
 def test_rbf_grad_float64_vs_oracle(ext, oracle, d, rffs, icpt, n):
-    """The float64 overload of cudaRBFGrad (double_precision = True kernels) on the float64 wave tiles (64 <= P <= 4096) and on the any-width
+    """The float64 overload of cudaRBFGrad (double_precision = True kernels) on the float64 wave tiles (P <= 4096) and on the any-width
     path beyond: same stage order and per-round `radem * norm` product, so the argument and `grad_val` are bit-identical to the oracle's in
     double and the outputs agree to the last digits of the two libms."""
     from oracle import oracle as orc
