@@ -456,3 +456,54 @@ def test_wide_transforms_under_load(oracle, n, d, m):
         rm = zf.T @ (zf @ v)
         assert float((a - rm).abs().max() / rm.abs().max()) < 1e-10
         del zf, zr
+
+
+@pytest.mark.parametrize("n,d,m", [(30_000, 4000, 8192), (50_001, 2003, 4000), (40_000, 1076, 8192), (60_000, 9, 8192)])
+def test_wave_tile_float64_and_gradient_operators_under_load(oracle, n, d, m):
+    """wave_tile_rbf_kernel (wave_f64.inc) at launch-filling sizes: the float64 feature operator, the float64 gradient operator and (padded
+    widths 2048 / 4096) the float32 gradient operator, whose wide transforms exchange tiles between the waves of a workgroup around workgroup
+    barriers.  (1) launches reproduce bit for bit, (2) sampled rows against the CPU oracle, (3) EVERY row: the gradient operator's feature
+    output equals the feature operator's rounded as the reference rounds it (two different kernels / modes on the same transform: a stale
+    tile in either shows in every frequency of its transform)."""
+    from xgpr_amd import xgpr_hip_rfgen_ext as ext
+    from xgpr_amd.kernels import make_kernel
+    k = make_kernel("RBF", (n, d), m, 123, DEV, {})
+    x32 = _data(n, d, seed=d + 1)
+    sigma = 1.3
+    rng = np.random.default_rng(n + d)
+    pick = np.sort(rng.choice(n, 96, replace=False))
+    pt = torch.from_numpy(pick).to(DEV)
+    radem_h = k.radem_diag.cpu().numpy()
+    scale = np.sqrt(1.0 / (m // 2 - 0.5))
+    o, g, o2, g2 = (torch.empty((n, m) + sh, dtype=torch.float64, device=DEV) for sh in ((), (1,), (), (1,)))
+    for dtype, tol in ((torch.float64, 1e-13), (torch.float32, 4e-7)):
+        x = x32.to(dtype)
+        chi = k.chi_arr.to(dtype)
+        ext.hipRBFGrad(x, o, g, k.radem_diag, chi, sigma, True)
+        ext.hipRBFGrad(x, o2, g2, k.radem_diag, chi, sigma, True)
+        assert torch.equal(o, o2) and torch.equal(g, g2) and bool(torch.isfinite(g).all())
+        ro, rg = np.zeros((96, m)), np.zeros((96, m, 1))
+        oracle.cpuRBFGrad(x[pt].cpu().numpy().copy(), ro, rg, radem_h, chi.cpu().numpy(), sigma, True)
+        assert np.abs(o[pt].cpu().numpy() - ro).max() <= tol * scale
+        assert np.abs(g[pt].cpu().numpy() - rg).max() <= (1e-13 if dtype == torch.float64 else 1e-6) * max(np.abs(rg).max(), scale)
+        # every row: the feature operator on sigma * x (the gradient operator multiplies the ARGUMENT by sigma, so only rows whose scaled
+        # input is exact in T compare bit for bit: sigma = 1 here)
+        ext.hipRBFGrad(x, o, g, k.radem_diag, chi, 1.0, True)
+        ext.hipRBFFeatureGen(x, o2, k.radem_diag, chi, True)
+        if dtype == torch.float64:
+            # cos_val = (T)(cos * scale) with T = double: the same product as the feature operator's -- bit for bit wherever both take the
+            # fast cos / sin (the gradient operator calls the library's: last-digit differences allowed, 4 ulp of the scale)
+            assert float((o - o2).abs().max()) <= 1e-15 * scale * 4
+        else:
+            assert float((o - o2).abs().max()) <= 4e-7 * scale
+    del o, g, o2, g2
+    # the float64 feature operator: reproducible, sampled rows against the oracle
+    xd = x32.double()
+    chid = k.chi_arr.double()
+    z, z2 = (torch.empty((n, m), dtype=torch.float64, device=DEV) for _ in range(2))
+    ext.hipRBFFeatureGen(xd, z, k.radem_diag, chid, True)
+    ext.hipRBFFeatureGen(xd, z2, k.radem_diag, chid, True)
+    assert torch.equal(z, z2)
+    ref = np.zeros((96, m))
+    oracle.cpuRBFFeatureGen(xd[pt].cpu().numpy().copy(), ref, radem_h, chid.cpu().numpy(), True)
+    assert np.abs(z[pt].cpu().numpy() - ref).max() <= 1e-13 * scale
