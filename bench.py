@@ -562,7 +562,13 @@ def wide_probe(device, rows=131072):
             for lo in range(0, rows, 32768):
                 ext.hipRBFFeatureGen(xs[lo:lo + 32768], z[:min(32768, rows - lo)], kern.radem_diag, kern.chi_arr, True)
         fg = ev_ms(featgen)
-        del z
+        # the float64 overload (double_precision=True kernels) and the gradient operator (features + d/dsigma), 32768 rows: wave tiles
+        # too since round 6 (wave_f64.inc)
+        xd, chid = xs[:32768].double(), kern.chi_arr.double()
+        f64 = ev_ms(lambda: ext.hipRBFFeatureGen(xd, z, kern.radem_diag, chid, True), reps=3)
+        grad = torch.empty(32768, m, 1, dtype=torch.float64, device=device)
+        gr32 = ev_ms(lambda: ext.hipRBFGrad(xs[:32768], z, grad, kern.radem_diag, kern.chi_arr, 1.0, True), reps=3)
+        del z, grad, xd
         vec = torch.randn(m, 1, dtype=torch.float64, device=device, generator=g)
         w = torch.zeros_like(vec)
         mv = ev_ms(lambda: ConjugateGrad(cache_features=False)._matvec(ds, kern, vec, w))
@@ -586,10 +592,12 @@ def wide_probe(device, rows=131072):
             "d": d, "num_rffs": m, "padded_width": 1 << int(np.ceil(np.log2(d))), "wave_tiles_per_transform": (1 << int(np.ceil(np.log2(d)))) // 1024,
             "matvec_plan": ext.ztz_matvec_plan(d, m // 2), "cache_features_auto": bool(kern.cache_pays()),
             "featgen_f64_ms": fg, "featgen_GBs": (4.0 * d + 8.0 * m) * rows / (fg * 1e-3) / 1e9,
+            "float64_input_op_ms_32768_rows": f64, "gradient_op_ms_32768_rows": gr32,
             "cg_matvec_regenerating_ms": mv, "cg_matvec_ns_per_tile": mv * 1e6 / tiles,
             "cg_matvec_cached_ms": mvc, "feature_cache_build_s": t_cache, "zty_ms": zty,
             "precond_build_rank512_s": t_pre, "achieved_ratio": float(pre.achieved_ratio),
-            "round5_tree": {"featgen_f64_ms": b.get("featgen_f32_ms"), "cg_matvec_ms": b.get("cg_matvec_ms"), "zty_ms": b.get("zty_ms"),
+            "round5_tree": {"featgen_f64_ms": b.get("featgen_f32_ms"), "float64_input_op_ms_32768_rows": b.get("featgen_f64_ms"),
+                            "cg_matvec_ms": b.get("cg_matvec_ms"), "zty_ms": b.get("zty_ms"),
                             "precond_build_rank512_s": None if "precond_build_rank512_ms" not in b else b["precond_build_rank512_ms"] * 1e-3,
                             "source": "profiles/r6_generic_path_before.json (generic_sorf_kernel + float64 Z + library GEMV; stored)"}})
         del pre, ds, kern, x, y, xs
