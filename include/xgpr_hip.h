@@ -118,7 +118,9 @@ int xgpr_rbf_grad_f64(const double *x, double *out, double *grad, const int8_t *
  * seqlen_host[nseq]: int32 on the HOST, as in the reference's CUDA module
  * (gpu_rf_gen/convolution_ops/rbf_convolution.h:19) -- validated there; seqlen_dev is the
  * same array on the device (the reference H2D-copies it on every call,
- * rbf_convolution.cu:368-379; here the caller owns that copy). */
+ * rbf_convolution.cu:368-379; here the caller owns that copy).
+ * Windows (conv_width * C, padded to P) up to 4096 elements run on wave-tile kernels for both element types (float32 up to
+ * 1024: wave_conv_kernel; float32 2048 / 4096 and float64: wave_tile_conv_kernel); wider windows on the any-width path. */
 int xgpr_conv1d_fgen_f32(const float *x, double *out, const int8_t *radem, const float *chi,
                          const int32_t *seqlen_host, const int32_t *seqlen_dev,
                          long n, long L, long C, long out_rows, long num_rffs, long num_freqs,

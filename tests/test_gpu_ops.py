@@ -303,6 +303,67 @@ def test_conv_vs_oracle(ext, oracle, L, C, cw, rffs, sc, n, amp):
     check_features(out, 2 * ref, 2 * scale)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("L,C,cw,rffs,sc,n", [
+    # float64: every padded window width (wave tiles, wave_f64.inc); float32 narrower than 2048: wave_conv_kernel (covered above too)
+    (30, 21, 9, 1024, 0, 9), (17, 4, 1, 64, 1, 21), (40, 21, 5, 600, 2, 7), (25, 8, 3, 2050, 0, 5), (20, 64, 8, 1024, 2, 5), (12, 3, 2, 4096, 1, 33),
+    # padded windows of 2048 / 4096 elements (two / four waves per transform; workgroups spanning two sequences of different lengths;
+    # a last workgroup with a spare pair: 3 sequences x 2 tiles)
+    (30, 128, 9, 2048, 1, 3), (40, 64, 20, 4096, 0, 7), (24, 128, 16, 1000, 2, 5), (50, 100, 30, 8192, 1, 4), (33, 21, 60, 2048, 1, 1),
+    (70, 64, 33, 4100, 0, 6)])
+def test_wave_tile_conv_operators_vs_oracle(ext, oracle, dtype, L, C, cw, rffs, sc, n):
+    """The convolution feature operator, its gradient and the max-pool operator on float64 input (every padded window width up to 4096)
+    and on float32 input with windows of 2048 / 4096 elements (wave_tile_conv_kernel): against the oracle; accumulate semantics (a second
+    call adds on top, the max-pool keeps the maximum); bit-reproducible."""
+    from oracle import oracle as orc
+    if L < cw:
+        L = cw + 3
+    rng = np.random.default_rng(L * C + rffs + cw)
+    dp = dtype == np.float64
+    radem, chi = orc.draw_sorf_params(rffs, cw * C, 77, conv=True, double_precision=dp)
+    x = rng.standard_normal((n, L, C)).astype(dtype)
+    sl = rng.integers(cw, L + 1, size=n).astype(np.int32)
+    sl[0] = L
+    kmax = int(sl.max()) - cw + 1
+    scale = np.sqrt(2.0 / rffs) * {0: kmax, 1: np.sqrt(kmax), 2: 1.0}[sc]
+    tol = 1e-13 if dp else 4e-7
+    ref = np.zeros((n, rffs))
+    oracle.cpuConv1dFGen(x, ref, radem, chi, sl, cw, sc)
+    out = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+    ext.hipConv1dFGen(dev(x), out, dev(radem), dev(chi), sl, cw, sc)
+    assert np.abs(out.cpu().numpy() - ref).max() <= tol * scale
+    again = torch.zeros_like(out)
+    ext.hipConv1dFGen(dev(x), again, dev(radem), dev(chi), sl, cw, sc)
+    assert torch.equal(out, again)
+    ext.hipConv1dFGen(dev(x), out, dev(radem), dev(chi), sl, cw, sc)
+    assert np.abs(out.cpu().numpy() - 2 * ref).max() <= 2 * tol * scale
+    # gradient
+    sigma = 0.8
+    ro, rg = np.zeros((n, rffs)), np.zeros((n, rffs, 1))
+    oracle.cpuConvGrad(x, ro, radem, chi, sl, rg, sigma, cw, sc)
+    o = torch.zeros((n, rffs), dtype=torch.float64, device=DEV)
+    g = torch.zeros((n, rffs, 1), dtype=torch.float64, device=DEV)
+    ext.hipConvGrad(dev(x), o, dev(radem), dev(chi), sl, g, sigma, cw, sc)
+    gt = 1e-12 if dp else 1e-6
+    assert np.abs(o.cpu().numpy() - ro).max() <= gt * np.abs(ro).max()
+    assert np.abs(g.cpu().numpy() - rg).max() <= gt * np.abs(rg).max()
+    # max-pool: F == M, the diagonal exactly reps * P long
+    P = 1 << max(1, int(np.ceil(np.log2(cw * C))))
+    m2 = max(P, (rffs // P) * P)
+    rng2 = np.random.default_rng(7)
+    radem2 = rng2.choice(np.array([-1, 1], dtype=np.int8), size=(3, 1, m2))
+    chi2 = np.abs(rng2.standard_normal(m2)).astype(dtype) + dtype(0.5)
+    refm = np.zeros((n, m2), dtype=np.float32)
+    oracle.cpuConv1dMaxpool(x, refm, radem2, chi2, sl, cw)
+    om = torch.zeros((n, m2), dtype=torch.float32, device=DEV)
+    ext.hipConv1dMaxpool(dev(x), om, dev(radem2), dev(chi2), sl, cw)
+    got = om.cpu().numpy()
+    if dp:
+        assert np.array_equal(got, refm)
+    else:
+        assert np.abs(got - refm).max() <= 1e-5 * np.abs(refm).max()
+
+
 def test_g4_maxpool_bit_exact(ext):
     g = load_golden("g4_maxpool.npz")
     for si in range(int(g["n_settings"])):
