@@ -135,5 +135,24 @@ for case in range(cases):
     kmax = int(sl.max()) - cw + 1
     cscale = np.sqrt(2.0 / m2) * {0: kmax, 1: np.sqrt(kmax), 2: 1.0}[sc]
     note("conv features", float(np.abs(oc.cpu().numpy() - refc).max()), 4e-7 * cscale)
+    # the same on float64 input (wave tiles at every window width, wave_f64.inc) and, every third case, a float32 window of 2048 / 4096
+    # elements (C = 128)
+    radem3, chi3 = orc.draw_sorf_params(m2, cw * C, 78, conv=True, double_precision=True)
+    refd = np.zeros((ns, m2))
+    oracle.cpuConv1dFGen(xs.astype(np.float64), refd, radem3, chi3, sl, cw, sc)
+    od = torch.zeros((ns, m2), dtype=torch.float64, device=dev)
+    ext.hipConv1dFGen(T(xs.astype(np.float64)), od, T(radem3), T(chi3), sl, cw, sc)
+    note("conv features f64", float(np.abs(od.cpu().numpy() - refd).max()), 1e-13 * cscale)
+    if case % 3 == 0:
+        Cw = 128; cww = int(rng.integers(9, 33)); Lw = cww + int(rng.integers(0, 12)); nsw = int(rng.integers(1, 12))
+        radem4, chi4 = orc.draw_sorf_params(m2, cww * Cw, 79, conv=True)
+        xw = rng.standard_normal((nsw, Lw, Cw)).astype(np.float32)
+        slw = rng.integers(cww, Lw + 1, size=nsw).astype(np.int32)
+        refw = np.zeros((nsw, m2))
+        oracle.cpuConv1dFGen(xw, refw, radem4, chi4, slw, cww, sc)
+        ow = torch.zeros((nsw, m2), dtype=torch.float64, device=dev)
+        ext.hipConv1dFGen(T(xw), ow, T(radem4), T(chi4), slw, cww, sc)
+        kw = int(slw.max()) - cww + 1
+        note("conv features wide f32", float(np.abs(ow.cpu().numpy() - refw).max()), 4e-7 * np.sqrt(2.0 / m2) * {0: kw, 1: np.sqrt(kw), 2: 1.0}[sc])
     print(f"case {case}: d={d} M={rffs} n={n} icpt={icpt} | conv C={C} w={cw} L={L} M={m2} ok", flush=True)
 print("worst error / bar per check:", {k: round(v, 3) for k, v in worst.items()})
