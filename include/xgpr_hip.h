@@ -67,9 +67,9 @@ int xgpr_srht_f64(double *x, const int8_t *radem, long n, long dim, long radem_l
  * chi[num_freqs] (T).  Like the reference's CUDA kernel (rbf_ops.cu:121-127) the output
  * is OVERWRITTEN: out[i, 2f] = s*cos(chi[f]*sorf(x_i)[f]), out[i, 2f+1] = s*sin(...).
  * float32 input, padded width P <= 4096: wave-tile kernels (a transform of P = 2048 / 4096 elements spans two / four
- * wave tiles with one cross-wave exchange per round); float64 input, P <= 4096: float64 wave tiles (16 doubles per
- * lane); beyond that: the any-width path (one workgroup per transform, butterflies in LDS).
- * The gradient operator (xgpr_rbf_grad_*) runs on wave tiles for the same widths.
+ * wave tiles with one cross-wave exchange per round); float64 input, P <= 8192: float64 wave tiles (16 doubles per
+ * lane), which also serve float32 input at P = 8192; beyond that: the any-width path (one workgroup per transform, butterflies in
+ * LDS).  The gradient operator (xgpr_rbf_grad_*) runs on wave tiles for the same widths.
  * Numerics: the float32 argument of every cos / sin is bit-identical to the reference's (same butterfly order, no
  * contraction).  For even log2(P) the three normalisers 2^(-log2(P)/2) are exact powers of two and are applied ONCE,
  * folded into chi: intermediate values of the transform are P^(1/2) .. P^(3/2) times the reference's (round by round), so

@@ -157,8 +157,10 @@ def test_rbf_vs_oracle(ext, oracle, d, rffs, icpt, n):
     # frequency; several transforms per row)
     (1025, 4096, True, 3), (2003, 4000, False, 3), (1076, 8192, True, 37), (2048, 2050, False, 5), (1500, 100, True, 11), (2049, 8192, True, 21),
     (4000, 8192, False, 19), (4096, 16384, True, 6), (3000, 1000, False, 9), (2500, 10000, True, 2),
-    # the any-width path: diagonals shorter than 64, padded width > 4096
-    (2, 16, False, 9), (5, 48, True, 12), (5000, 8192, True, 2)])
+    # padded width 8192: eight waves = one workgroup per transform
+    (5000, 8192, True, 2), (8192, 16384, False, 5), (4097, 1000, True, 7), (6000, 20000, True, 3),
+    # the any-width path: diagonals shorter than 64, padded width > 8192
+    (2, 16, False, 9), (5, 48, True, 12), (9000, 16384, True, 2)])
 def test_rbf_float64_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """The float64 overload of the feature operator (double_precision = True kernels, kernel_baseclass.py:278-285) against the oracle
     in double: same butterfly order and per-round `radem * norm` product as shared_rfgen_ops.cpp:51-78, so the cos / sin arguments are
@@ -532,8 +534,10 @@ def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
                                            # padded widths 2048 / 4096: two / four waves of a workgroup per transform (wave_f64.inc, T = float)
                                            (2003, 4000, False, 7), (1076, 8192, True, 3), (1500, 100, False, 11), (4000, 8192, True, 5),
                                            (4096, 4100, False, 6), (3000, 16384, True, 2),
+                                           # padded width 8192 (eight waves per transform)
+                                           (5000, 8192, True, 2), (8192, 16384, False, 3), (6000, 300, True, 5),
                                            # the any-width path
-                                           (5000, 8192, True, 2)])
+                                           (9000, 16384, True, 2)])
 def test_rbf_grad_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """cudaRBFGrad on the wave kernels (P <= 4096) and the any-width path: features and d/dsigma against
     the oracle, including the reference's roundings back to float (shared_rfgen_ops.cpp:140-155)."""
@@ -556,7 +560,7 @@ def test_rbf_grad_vs_oracle(ext, oracle, d, rffs, icpt, n):
                                            (1024, 8192, True, 33), (1076, 8192, True, 7), (2003, 4000, False, 3), (4000, 8192, False, 9),
                                            (3000, 1000, True, 6), (33, 64, False, 9), (5000, 8192, True, 2),
                                            (9, 8192, True, 77), (3, 2048, False, 31), (2, 128, True, 5), (20, 4096, True, 130), (32, 512, False, 9),
-                                           (7, 16, False, 4)])
+                                           (7, 16, False, 4), (8000, 16384, False, 3), (4100, 8192, True, 4), (9000, 16384, True, 2)])
 def test_rbf_grad_float64_vs_oracle(ext, oracle, d, rffs, icpt, n):
     """The float64 overload of cudaRBFGrad (double_precision = True kernels) on the float64 wave tiles (P <= 4096) and on the any-width
     path beyond: same stage order and per-round `radem * norm` product, so the argument and `grad_val` are bit-identical to the oracle's in
