@@ -563,7 +563,7 @@ def wide_probe(device, rows=131072):
                 ext.hipRBFFeatureGen(xs[lo:lo + 32768], z[:min(32768, rows - lo)], kern.radem_diag, kern.chi_arr, True)
         fg = ev_ms(featgen)
         # the float64 overload (double_precision=True kernels) and the gradient operator (features + d/dsigma), 32768 rows: wave tiles
-        # too since round 6 (wave_f64.inc)
+        # too since round 6 (wave_tile.inc)
         xd, chid = xs[:32768].double(), kern.chi_arr.double()
         f64 = ev_ms(lambda: ext.hipRBFFeatureGen(xd, z, kern.radem_diag, chid, True), reps=3)
         grad = torch.empty(32768, m, 1, dtype=torch.float64, device=device)

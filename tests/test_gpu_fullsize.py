@@ -460,7 +460,7 @@ def test_wide_transforms_under_load(oracle, n, d, m):
 
 @pytest.mark.parametrize("n,d,m", [(30_000, 4000, 8192), (50_001, 2003, 4000), (40_000, 1076, 8192), (60_000, 9, 8192)])
 def test_wave_tile_float64_and_gradient_operators_under_load(oracle, n, d, m):
-    """wave_tile_rbf_kernel (wave_f64.inc) at launch-filling sizes: the float64 feature operator, the float64 gradient operator and (padded
+    """wave_tile_rbf_kernel (wave_tile.inc) at launch-filling sizes: the float64 feature operator, the float64 gradient operator and (padded
     widths 2048 / 4096) the float32 gradient operator, whose wide transforms exchange tiles between the waves of a workgroup around workgroup
     barriers.  (1) launches reproduce bit for bit, (2) sampled rows against the CPU oracle, (3) EVERY row: the gradient operator's feature
     output equals the feature operator's rounded as the reference rounds it (two different kernels / modes on the same transform: a stale

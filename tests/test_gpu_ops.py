@@ -148,7 +148,7 @@ def test_rbf_vs_oracle(ext, oracle, d, rffs, icpt, n):
 
 
 @pytest.mark.parametrize("d,rffs,icpt,n", [
-    # float64 wave tiles (padded width <= 4096, wave_f64.inc): every width, ragged rows and tiles, several transforms per tile
+    # float64 wave tiles (padded width <= 4096, wave_tile.inc): every width, ragged rows and tiles, several transforms per tile
     (7, 512, False, 17), (32, 512, True, 200), (9, 8192, True, 77), (3, 2048, False, 31), (2, 128, True, 5), (20, 4096, True, 130), (16, 1000, False, 9),
     (40, 3000, True, 21),
     (33, 64, False, 9), (64, 2048, True, 70), (100, 300, False, 13), (128, 4096, True, 40), (200, 1026, False, 21), (256, 4096, True, 300),
@@ -307,7 +307,7 @@ def test_conv_vs_oracle(ext, oracle, L, C, cw, rffs, sc, n, amp):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("L,C,cw,rffs,sc,n", [
-    # float64: every padded window width (wave tiles, wave_f64.inc); float32 narrower than 2048: wave_conv_kernel (covered above too)
+    # float64: every padded window width (wave tiles, wave_tile.inc); float32 narrower than 2048: wave_conv_kernel (covered above too)
     (30, 21, 9, 1024, 0, 9), (17, 4, 1, 64, 1, 21), (40, 21, 5, 600, 2, 7), (25, 8, 3, 2050, 0, 5), (20, 64, 8, 1024, 2, 5), (12, 3, 2, 4096, 1, 33),
     # padded windows of 2048 / 4096 elements (two / four waves per transform; workgroups spanning two sequences of different lengths;
     # a last workgroup with a spare pair: 3 sequences x 2 tiles)
@@ -531,7 +531,7 @@ def test_feature_cache_and_cached_matvec(ext, oracle, d, rffs, icpt, n):
 
 @pytest.mark.parametrize("d,rffs,icpt,n", [(50, 128, False, 11), (256, 4096, True, 30), (856, 4000, True, 7),
                                            (1024, 8192, False, 9), (1100, 2048, True, 5),
-                                           # padded widths 2048 / 4096: two / four waves of a workgroup per transform (wave_f64.inc, T = float)
+                                           # padded widths 2048 / 4096: two / four waves of a workgroup per transform (wave_tile.inc, T = float)
                                            (2003, 4000, False, 7), (1076, 8192, True, 3), (1500, 100, False, 11), (4000, 8192, True, 5),
                                            (4096, 4100, False, 6), (3000, 16384, True, 2),
                                            # padded width 8192 (eight waves per transform)

@@ -33,7 +33,7 @@ def rows():
 
 def test_no_kernel_uses_scratch(rows):
     """No scratch memory anywhere; no VGPR held outside the vector registers either -- with one named exception: the float64 convolution
-    operators on wave tiles (wave_f64.inc, off the fit path) carry 64 (gradient mode: 128) accumulator registers per lane through the
+    operators on wave tiles (wave_tile.inc, off the fit path) carry 64 (gradient mode: 128) accumulator registers per lane through the
     k-mer loop on top of a float64 tile, and the compiler parks part of them in accumulation registers (v_accvgpr moves, ScratchSize 0)."""
     assert len(rows) > 200
     bad = [(r["name"], r["ScratchSize"]) for r in rows if r.get("ScratchSize", 0)]

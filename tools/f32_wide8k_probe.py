@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The float32 feature operator at padded width 8192 (wave tiles, eight waves per transform: wave_f64.inc) through whichever library
+"""The float32 feature operator at padded width 8192 (wave tiles, eight waves per transform: wave_tile.inc) through whichever library
 XGPR_HIP_LIB names; XGPR_F64_PLAN=generic: the any-width path."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

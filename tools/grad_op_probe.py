@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The gradient operator (hipRBFGrad: features and d/dsigma, cudaRBFGrad's drop-in) on float32 and float64 input through whichever
 library XGPR_HIP_LIB names: time per 32768 rows and checksums.
-    python tools/grad_op_probe.py [d] [num_rffs]      (XGPR_F64_PLAN=generic: the any-width path for the shapes wave_f64.inc serves)"""
+    python tools/grad_op_probe.py [d] [num_rffs]      (XGPR_F64_PLAN=generic: the any-width path for the shapes wave_tile.inc serves)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch

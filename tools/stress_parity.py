@@ -135,7 +135,7 @@ for case in range(cases):
     kmax = int(sl.max()) - cw + 1
     cscale = np.sqrt(2.0 / m2) * {0: kmax, 1: np.sqrt(kmax), 2: 1.0}[sc]
     note("conv features", float(np.abs(oc.cpu().numpy() - refc).max()), 4e-7 * cscale)
-    # the same on float64 input (wave tiles at every window width, wave_f64.inc) and, every third case, a float32 window of 2048 / 4096
+    # the same on float64 input (wave tiles at every window width, wave_tile.inc) and, every third case, a float32 window of 2048 / 4096
     # elements (C = 128)
     radem3, chi3 = orc.draw_sorf_params(m2, cw * C, 78, conv=True, double_precision=True)
     refd = np.zeros((ns, m2))

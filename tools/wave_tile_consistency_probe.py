@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Many launches of the wave-tile operators whose wide transforms exchange tiles between the waves of a workgroup (wave_f64.inc): the
+"""Many launches of the wave-tile operators whose wide transforms exchange tiles between the waves of a workgroup (wave_tile.inc): the
 float64 feature operator, the float32 / float64 gradient operators and the float32 / float64 convolution operator at padded widths
 2048 / 4096, each launch compared bit for bit with the first one (a cross-wave ordering that fails does so in a few launches per hundred,
 under load -- tools/wide_consistency_probe.py found the fused kernel's that way).

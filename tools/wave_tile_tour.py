@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One call of every operator / shape family the wave-tile kernels of wave_f64.inc serve (for a rocprofv3 --kernel-trace --stats summary:
+"""One call of every operator / shape family the wave-tile kernels of wave_tile.inc serve (for a rocprofv3 --kernel-trace --stats summary:
 profiles/r6_wave_tile_kernel_stats.csv): float64 features and gradient at d = 9 / 1024 / 2003 / 4000 / 5000, float32 gradient and
 features at the widths they take there, the convolution operators on float64 input and on float32 windows of 2048 / 4096 elements."""
 import os, sys

@@ -51,7 +51,7 @@ namespace {
 #include "generic_fht.inc"
 #include "wave_sorf.inc"
 #include "wave_kernels.inc"
-#include "wave_f64.inc"
+#include "wave_tile.inc"
 #include "fused_ztz.inc"
 #include "zcache.inc"
 #include "zblock.inc"
